@@ -1,0 +1,64 @@
+"""Pins the oracle (oracle/rt_oracle.c, a CPU restatement) to the unmodified reference.
+
+tests/golden/ref_kats.json holds, per known-answer configuration, the md5 of the PPM written by the
+reference binary and the counters it printed (produced by oracle/gen_ref_kats.py in a container that
+has the reference checkout).  The oracle, run in its sequential legacy-rand() mode on the committed
+scene dumps, must reproduce every one of them exactly."""
+import json
+import os
+
+import pytest
+
+from conftest import CAMERAS, GOLDEN
+
+with open(os.path.join(GOLDEN, "ref_kats.json")) as f:
+    KATS = json.load(f)
+
+FAST = [k for k in sorted(KATS) if k != "K8"]
+
+
+def run_kat(orc, scenes, name):
+    k = KATS[name]
+    sp = k["spec"]
+    sc = scenes[sp["scene"]]
+    tree = orc.Octree(sc, sp.get("tri_per_bb", 16), sp.get("ads_depth", 10))
+    cfg = orc.make_cfg(fov=0.6, width=sp["w"], height=sp["h"], spp=sp.get("spp", 1), spt=sp.get("spt", 1),
+                       render_type=sp["render_type"], shading=sp["shading"], cull=sp.get("cull", True), ads=sp["ads"],
+                       rng_mode=orc.RNG_LEGACY, **CAMERAS[sp["scene"]])
+    rgb, tri, t, st = orc.render(sc, tree, cfg)
+    return k, sp, tree, rgb, st
+
+
+@pytest.mark.parametrize("name", FAST + [pytest.param("K8", marks=pytest.mark.slow)])
+def test_reference_image_and_counters(orc, scenes, name):
+    k, sp, tree, rgb, st = run_kat(orc, scenes, name)
+    assert orc.ppm_md5(rgb) == k["ppm_md5"]
+    assert st.search_calls == k["search_calls"]
+    assert st.search_returned == k["search_returned"]
+    assert st.tri_tests == k["tri_tests"]
+    if sp["ads"] == "octree":
+        assert st.search_nodes == k["search_nodes"]
+        assert st.search_leaves == k["search_leaves"]
+        ts = tree.stats()
+        for key in ("nodes", "leaves", "max_depth", "max_tris_in_leaf"):
+            assert ts[key] == k[key], key
+        assert abs(ts["avg_leaf_depth"] - k["avg_leaf_depth"]) < 1e-4
+        assert abs(ts["avg_tris_in_leaf"] - k["avg_tris_in_leaf"]) < 1e-3
+
+
+def test_published_tree_shape(orc, scenes):
+    """report/report.tex:178-186 of the reference: 1,584 nodes / 1,300 leaves / 5.22 / 34 / 7.03."""
+    ts = orc.Octree(scenes["sphere"], 16, 10).stats()
+    assert (ts["nodes"], ts["leaves"], ts["max_tris_in_leaf"], ts["max_depth"]) == (1584, 1300, 34, 10)
+    assert round(ts["avg_leaf_depth"], 2) == 5.22 and round(ts["avg_tris_in_leaf"], 2) == 7.03
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/res"), reason="reference checkout absent")
+def test_scene_dumps_match_obj_files(orc, scenes):
+    import numpy as np
+    for key, fn in (("original", "CornellBox-Original.obj"), ("sphere", "CornellBox-Sphere.obj")):
+        s = orc.Scene.from_obj("/root/reference/res/" + fn, "/root/reference/res/")
+        d = scenes[key]
+        assert np.array_equal(s.pos, d.pos) and np.array_equal(s.matid, d.matid)
+        assert np.array_equal(s.materials, d.materials) and np.array_equal(s.norm, d.norm)
+        assert list(s.light_tri) == list(d.light_tri)
