@@ -1,0 +1,199 @@
+/*
+ * raytracer_amd.h -- C ABI of the MI355X (gfx950) ray-scene query backend.
+ *
+ * This is the boundary a host renderer binds to: plain pointers and sizes, no C++
+ * types, no exceptions.  Every entry point cites the interface of the reference
+ * ray tracer that it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - All functions return 0 on success, a negative rt_status on failure;
+ *    rt_last_error() then returns a thread-local message.
+ *  - `mem` arguments say where the caller's ray / result buffers live:
+ *    RT_MEM_HOST (the library stages them) or RT_MEM_DEVICE (used in place;
+ *    must belong to the handle's device).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    Calls with device buffers are asynchronous on that stream unless they return
+ *    counts; calls with host buffers return after the results are in the buffers.
+ *  - A handle is bound to one device and must be used from one host thread at a
+ *    time, like the reference's Ads object (its counters are plain mutable fields,
+ *    src/ADS/Octree/octree.h:55-61).
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ads rt_ads; /* opaque: one acceleration data structure resident on one GPU */
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / unknown name (renderer.cc:355,364,375 throw runtime_error) */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    RT_ERR_BUILD = -3,       /* octree invariant violated (octree.cc:124-152 prints and exit(1)s) */
+    RT_ERR_NOT_BUILT = -4,   /* query before rt_ads_build */
+    RT_ERR_CAPACITY = -5,    /* caller's output buffer too small */
+    RT_ERR_UNSUPPORTED = -6
+};
+
+enum rt_mem { RT_MEM_HOST = 0, RT_MEM_DEVICE = 1 };
+
+/* Renderer::ACCELERATION_DATA_STRUCTURE (src/Renderer/renderer.h:24) extended by one value.  The config
+ * string for it, under the reference's own (misspelled) key "acceleratied_data_structure"."name"
+ * (renderer.cc:368-376), is "octree_gpu". */
+enum rt_ads_kind { RT_ADS_NONE = 0, RT_ADS_OCTREE = 1, RT_ADS_OCTREE_PARAMETRIC = 2, RT_ADS_OCTREE_GPU = 3 };
+/* Renderer::RENDER_TYPE / SHADING_TYPE (src/Renderer/renderer.h:22-23) */
+enum rt_render_type { RT_RENDER_DISTANCE = 0, RT_RENDER_DIFFUSION = 1, RT_RENDER_PHONG = 2, RT_RENDER_BLINN_PHONG = 3 };
+enum rt_shading_type { RT_SHADING_FLAT = 0, RT_SHADING_SMOOTH = 1 };
+/* Primary-ray frame: RT_ASPECT_COMPAT keeps the reference's integer `height / width`
+ * (renderer.cc:93); RT_ASPECT_TRUE uses the real ratio. */
+enum rt_aspect_mode { RT_ASPECT_COMPAT = 0, RT_ASPECT_TRUE = 1 };
+
+/* Maps a config name to rt_ads_kind; returns RT_ERR_INVALID for unknown names
+ * (renderer.cc:374-376: "Invalid data structure"). */
+int rt_ads_kind_from_name(const char* name, int* out_kind);
+
+/* Octree::config_setup (src/ADS/Octree/octree.cc:268-275): the two tuning keys of the
+ * "acceleratied_data_structure" object, plus the device to live on. */
+typedef struct rt_ads_config {
+    uint32_t struct_size;           /* = sizeof(rt_ads_config) */
+    int32_t device;                 /* HIP device ordinal */
+    uint32_t max_triangles_per_bb;  /* "max_triangles_per_BB" */
+    uint32_t max_depth;             /* "max_depth" */
+} rt_ads_config;
+
+/* Ads::Ads + Octree::Octree (src/ADS/ads.h:18, src/ADS/Octree/octree.h:17). */
+int rt_ads_create(const rt_ads_config* cfg, rt_ads** out);
+/* Ads::~Ads (src/ADS/ads.h:19): frees host and device memory. */
+void rt_ads_destroy(rt_ads* ads);
+
+/* Ads::Build / Octree::Build (src/ADS/ads.h:21, src/ADS/Octree/octree.cc:19-171).
+ * positions: n_triangles x 3 vertices x 3 floats, host memory, triangle order = the order of the
+ * reference's Scene::GetTriangles().  The data is copied; the caller may free it afterwards.
+ * Builds the octree on the host with the reference's exact splitting rule, flattens it in
+ * breadth-first order and uploads it.  n_triangles == 0 is accepted (octree.cc:24-27); queries
+ * then report no candidates. */
+int rt_ads_build(rt_ads* ads, const float* positions, uint64_t n_triangles);
+
+/* Octree::PrintStats / calculate_stats, structural part (src/ADS/Octree/octree.cc:209-266). */
+typedef struct rt_tree_stats {
+    uint64_t max_depth, nodes, leaves, max_triangles_in_leaf;
+    float avg_leaf_depth, avg_triangles_in_leaf;
+    uint64_t leaf_refs;        /* triangle references summed over all leaves */
+    uint64_t internal_nodes;
+    double build_seconds;      /* octree.cc:168-170 */
+    uint64_t device_bytes;     /* size of the flattened structure in HBM */
+} rt_tree_stats;
+int rt_ads_tree_stats(const rt_ads* ads, rt_tree_stats* out);
+
+/* Query counters, as printed by Octree::PrintStats (octree.cc:218-223); they accumulate
+ * over every query call on the handle until reset. */
+typedef struct rt_query_stats {
+    uint64_t search_calls;     /* "Search method call count": one per ray */
+    uint64_t closest_rays, any_rays;
+} rt_query_stats;
+int rt_ads_query_stats(const rt_ads* ads, rt_query_stats* out);
+int rt_ads_reset_query_stats(rt_ads* ads);
+
+/* Ads::Search (src/ADS/ads.h:22, src/ADS/Octree/octree.cc:173-207) for a batch of rays.
+ * For ray i the candidate triangle indices, in exactly the reference's order (leaves in breadth-first
+ * visiting order, duplicates kept), are written to out_tri[out_offsets[i] .. out_offsets[i+1]).
+ * rays: n x 6 floats (origin xyz, direction xyz), host memory.  out_offsets: n+1 entries.
+ * If the total exceeds cap, RT_ERR_CAPACITY is returned and *out_total holds the size needed. */
+int rt_ads_search(rt_ads* ads, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap,
+                  uint64_t* out_total);
+
+/* Ads::Search + the closest-hit loop of Renderer::ray_color (src/Renderer/renderer.cc:116-142) for n rays.
+ * origins, dirs: n x 3 floats.  out_t[i] = hit distance or +inf; out_tri[i] = index of the winning
+ * triangle in Build order, or -1.  Ties in t go to the triangle that comes first in the reference's
+ * candidate list. */
+int rt_ads_trace_closest(rt_ads* ads, const float* origins, const float* dirs, uint64_t n, int cull_backfaces, int mem,
+                         float* out_t, int32_t* out_tri, void* stream);
+
+/* Ads::Search + the any-hit loop of Renderer::is_shadowed (src/Renderer/renderer.cc:288-313) for n
+ * (surface point, light point) pairs: out_shadowed[i] = 1 if some candidate is hit at
+ * epsilon <= t < |light - point|. */
+int rt_ads_trace_any(rt_ads* ads, const float* points, const float* lights, uint64_t n, int cull_backfaces, int mem,
+                     uint8_t* out_shadowed, void* stream);
+
+/* Per-triangle shading inputs and the material table (Triangle::vertices[].norm, Triangle::material_id,
+ * src/triangle.h:10-14; Material, src/material.h:7-16 as 18 floats: ambient, diffuse, specular,
+ * transmittance, emission, shininess, ior, dissolve).  normals may be NULL (flat shading only,
+ * obj_loader.cc:161-163).  Triangles whose material emits become the light list in Build order
+ * (obj_loader.cc:188-191).  Call after rt_ads_build. */
+int rt_scene_set_shading(rt_ads* ads, const float* normals, const int32_t* material_ids, const float* materials,
+                         uint32_t n_materials);
+
+/* Renderer::config_setup + Camera (src/Renderer/renderer.cc:337-379, src/camera.h:15-21). */
+typedef struct rt_render_config {
+    uint32_t struct_size;        /* = sizeof(rt_render_config) */
+    float cam_pos[3], cam_up[3], cam_dir[3];
+    float fov;
+    int32_t width, height, samples_per_pixel;
+    int32_t max_depth;            /* "max_depth" of the renderer: recursion limit */
+    int32_t samples_per_triangle;
+    int32_t render_type;          /* rt_render_type */
+    int32_t shading_type;         /* rt_shading_type */
+    int32_t cull_backfaces;
+    float max_distance;
+    float background[3];
+    int32_t aspect_mode;          /* rt_aspect_mode */
+    uint32_t seed;                /* counter-based generator key ("seed" of the config) */
+    /* Image partition for multi-GPU: the image is cut into bands of 8 pixel rows (one row of 8x8
+     * wavefront tiles); this call renders the bands b with b % band_world == band_rank. */
+    int32_t band_rank, band_world;
+} rt_render_config;
+
+typedef struct rt_render_stats {
+    uint64_t primary_rays, secondary_rays, shadow_rays; /* each is one Search-equivalent query */
+    uint64_t rays;                /* sum of the three */
+    uint32_t levels;              /* recursion levels that had work */
+    float ms_closest, ms_shade, ms_resolve, ms_total; /* device time by kernel class (HIP events) */
+    uint32_t launches_closest, launches_shade;
+} rt_render_stats;
+
+/* Renderer::RenderScene's hot loop (src/Renderer/renderer.cc:37-52) on the device: primary rays
+ * (renderer.cc:82-112), closest hit, local illumination with area-light shadow samples
+ * (renderer.cc:202-247, 288-313), reflection / refraction recursion (renderer.cc:170-192,315-335),
+ * fuzzysampling (renderer.cc:43-49).  Random numbers come from a counter-based generator keyed by
+ * (seed, pixel, sample, path node, light, light sample, dimension), so the image does not depend on
+ * how the work is partitioned.  out_rgb: height x width x 3 floats (clamped colours as the reference
+ * stores them before write_color); only the pixels of this call's bands are written. */
+int rt_render(rt_ads* ads, const rt_render_config* cfg, float* out_rgb, int mem, rt_render_stats* stats, void* stream);
+
+/* Primary-ray closest hits only (sample 0, no shading): per pixel t and triangle index. */
+int rt_render_primary_hits(rt_ads* ads, const rt_render_config* cfg, float* out_t, int32_t* out_tri, int mem, void* stream);
+
+/* The shared counter-based generator, exposed so that host code can reproduce a sample:
+ * returns the 31-bit integer k; the float is (float)k / (float)2147483647. */
+uint32_t rt_rng_u31(uint32_t seed, uint32_t pixel, uint32_t spp_sample, uint32_t node_id, uint32_t light, uint32_t sample,
+                    uint32_t dim);
+
+/* ---- host-only view of Build, no GPU needed ------------------------------------------------------------
+ * The octree exactly as rt_ads_build constructs it before the upload (Octree::Build,
+ * src/ADS/Octree/octree.cc:19-171): nodes in the reference's queue (breadth-first) order with their
+ * boxes, child links (octant 0..7, -1 = null) and triangle index lists, plus the flattened device
+ * layout (256-byte internal-node records, 48-byte leaf-slot records).  For inspection and tests. */
+typedef struct rt_host_tree rt_host_tree;
+int rt_host_tree_build(const float* positions, uint64_t n_triangles, uint32_t max_triangles_per_bb, uint32_t max_depth,
+                       rt_host_tree** out);
+void rt_host_tree_destroy(rt_host_tree* t);
+int rt_host_tree_sizes(const rt_host_tree* t, uint64_t* n_nodes, uint64_t* n_pool, uint64_t* n_records, uint64_t* n_slots,
+                       uint32_t* max_stack);
+int rt_host_tree_export(const rt_host_tree* t, uint8_t* is_leaf, uint32_t* depth, float* bmin, float* bmax, int32_t* child8,
+                        uint64_t* tri_begin, uint32_t* tri_count, uint32_t* pool);
+int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info2);
+int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out);
+
+const char* rt_last_error(void);
+/* Library / device identification, for logs. */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

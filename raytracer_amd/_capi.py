@@ -1,0 +1,117 @@
+"""ctypes binding of raytracer_amd/lib/libraytracer_amd.so (the C ABI in include/raytracer_amd.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing any entry
+point raises.  PyTorch is not needed here; callers that hold device tensors pass raw pointers.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libraytracer_amd.so")
+
+RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+RT_ADS_NONE, RT_ADS_OCTREE, RT_ADS_OCTREE_PARAMETRIC, RT_ADS_OCTREE_GPU = 0, 1, 2, 3
+RENDER_TYPES = {"distance": 0, "diffusion": 1, "phong": 2, "blinn_phong": 3}
+SHADING_TYPES = {"flat": 0, "smooth": 1}
+RT_ASPECT_COMPAT, RT_ASPECT_TRUE = 0, 1
+
+
+class AdsConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_triangles_per_bb", C.c_uint32),
+                ("max_depth", C.c_uint32)]
+
+
+class TreeStats(C.Structure):
+    _fields_ = [("max_depth", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
+                ("max_triangles_in_leaf", C.c_uint64), ("avg_leaf_depth", C.c_float),
+                ("avg_triangles_in_leaf", C.c_float), ("leaf_refs", C.c_uint64), ("internal_nodes", C.c_uint64),
+                ("build_seconds", C.c_double), ("device_bytes", C.c_uint64)]
+
+
+class QueryStats(C.Structure):
+    _fields_ = [("search_calls", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64)]
+
+
+class RenderConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("cam_pos", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_dir", C.c_float * 3),
+        ("fov", C.c_float),
+        ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32),
+        ("max_depth", C.c_int32), ("samples_per_triangle", C.c_int32),
+        ("render_type", C.c_int32), ("shading_type", C.c_int32), ("cull_backfaces", C.c_int32),
+        ("max_distance", C.c_float), ("background", C.c_float * 3),
+        ("aspect_mode", C.c_int32), ("seed", C.c_uint32),
+        ("band_rank", C.c_int32), ("band_world", C.c_int32),
+    ]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("rays", C.c_uint64), ("levels", C.c_uint32),
+                ("ms_closest", C.c_float), ("ms_shade", C.c_float), ("ms_resolve", C.c_float), ("ms_total", C.c_float),
+                ("launches_closest", C.c_uint32), ("launches_shade", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/raytracer_amd.h declares
+EXPORTS = [
+    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_tree_stats",
+    "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_search", "rt_ads_trace_closest", "rt_ads_trace_any",
+    "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
+    "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
+    "rt_host_tree_export_flat", "rt_host_tree_stats",
+]
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"raytracer_amd error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                          "(there is no CPU fallback for the query path)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_version.restype = C.c_char_p
+    L.rt_ads_kind_from_name.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    L.rt_ads_create.argtypes = [C.POINTER(AdsConfig), C.POINTER(vp)]
+    L.rt_ads_destroy.argtypes = [vp]
+    L.rt_ads_destroy.restype = None
+    L.rt_ads_build.argtypes = [vp, vp, C.c_uint64]
+    L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
+    L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
+    L.rt_ads_reset_query_stats.argtypes = [vp]
+    L.rt_ads_search.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rt_ads_trace_closest.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
+    L.rt_ads_trace_any.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp]
+    L.rt_scene_set_shading.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.rt_render.argtypes = [vp, C.POINTER(RenderConfig), vp, C.c_int, C.POINTER(RenderStats), vp]
+    L.rt_render_primary_hits.argtypes = [vp, C.POINTER(RenderConfig), vp, vp, C.c_int, vp]
+    L.rt_host_tree_build.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.rt_host_tree_destroy.argtypes = [vp]
+    L.rt_host_tree_destroy.restype = None
+    L.rt_host_tree_sizes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4 + [C.POINTER(C.c_uint32)]
+    L.rt_host_tree_export.argtypes = [vp] * 9
+    L.rt_host_tree_export_flat.argtypes = [vp, vp, vp, vp]
+    L.rt_host_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
+    L.rt_rng_u31.restype = C.c_uint32
+    L.rt_rng_u31.argtypes = [C.c_uint32] * 7
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RtError(rc, lib().rt_last_error().decode())

@@ -1,0 +1,345 @@
+// host_octree.cpp -- see host_octree.h.
+#include "host_octree.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace rt {
+
+f3 face_normal(const f3 v[3]) {
+    // src/triangle.h:28-32: cross(b - a, c - b), normalised with the guarded division.
+    return normalize(cross(v[1] - v[0], v[2] - v[1]));
+}
+
+namespace {
+
+// std::min({a,b,c}) / std::max({a,b,c}) return the first smallest / largest element.
+inline float min3(float a, float b, float c) {
+    float m = a;
+    if (b < m) m = b;
+    if (c < m) m = c;
+    return m;
+}
+inline float max3(float a, float b, float c) {
+    float m = a;
+    if (m < b) m = b;
+    if (m < c) m = c;
+    return m;
+}
+
+inline bool axis_separates(f3 axis, f3 v0, f3 v1, f3 v2, f3 half) {
+    const float p0 = dot(v0, axis), p1 = dot(v1, axis), p2 = dot(v2, axis);
+    const float r = half.x * fabsf(axis.x) + half.y * fabsf(axis.y) + half.z * fabsf(axis.z);
+    return min3(p0, p1, p2) > r || max3(p0, p1, p2) < -r;
+}
+
+}  // namespace
+
+bool tri_box_overlap(const f3 v[3], f3 normal, f3 bmin, f3 bmax) {
+    const f3 center = (bmin + bmax) * 0.5f;
+    const f3 half = (bmax - bmin) * 0.5f;
+    const f3 v0 = v[0] - center, v1 = v[1] - center, v2 = v[2] - center;
+    const f3 e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+    // 1. box axes
+    for (int i = 0; i < 3; ++i) {
+        const float mn = min3(comp(v0, i), comp(v1, i), comp(v2, i));
+        const float mx = max3(comp(v0, i), comp(v1, i), comp(v2, i));
+        if (mn > comp(half, i) || mx < -comp(half, i)) return false;
+    }
+    // 2. triangle plane, with the stored (normalised) face normal
+    const float p0 = dot(v0, normal);
+    const float r = half.x * fabsf(normal.x) + half.y * fabsf(normal.y) + half.z * fabsf(normal.z);
+    if (fabsf(p0) > r) return false;
+    // 3. nine edge cross products, in the reference's order
+    const f3 axes[9] = {mk(0, -e0.z, e0.y), mk(0, -e1.z, e1.y), mk(0, -e2.z, e2.y), mk(e0.z, 0, -e0.x), mk(e1.z, 0, -e1.x),
+                        mk(e2.z, 0, -e2.x), mk(-e0.y, e0.x, 0), mk(-e1.y, e1.x, 0), mk(-e2.y, e2.x, 0)};
+    for (const f3& a : axes)
+        if (axis_separates(a, v0, v1, v2, half)) return false;
+    return true;
+}
+
+namespace {
+
+struct TriGeom {
+    f3 v[3];
+    f3 n;
+};
+
+struct Split {  // work of one frontier node
+    f3 cmin[8], cmax[8];
+    std::vector<uint32_t> list[8];
+};
+
+unsigned worker_count() {
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) {
+        int v = std::atoi(e);
+        if (v > 0) return (unsigned)v;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    return std::min(hw, 16u);
+}
+
+template <class F>
+void parallel_for(size_t n, unsigned workers, F&& f) {
+    if (workers <= 1 || n <= 1) {
+        for (size_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    const unsigned k = (unsigned)std::min<size_t>(workers, n);
+    pool.reserve(k);
+    for (unsigned w = 0; w < k; ++w)
+        pool.emplace_back([&] {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto& t : pool) t.join();
+}
+
+}  // namespace
+
+bool build_octree(const float* positions, uint64_t n, uint32_t max_per_bb, uint32_t max_depth, HostOctree& out,
+                  std::string& err) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    out = HostOctree();
+    if (n == 0) return true;  // octree.cc:24-27
+    out.empty = false;
+
+    std::vector<TriGeom> tris(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int v = 0; v < 3; ++v) tris[i].v[v] = mk(positions[i * 9 + v * 3], positions[i * 9 + v * 3 + 1], positions[i * 9 + v * 3 + 2]);
+        tris[i].n = face_normal(tris[i].v);
+    }
+
+    const float aabb_eps = 1e-6f;  // octree.cc:30
+    f3 mn = tris[0].v[0], mx = tris[0].v[0];  // octree.cc:33-44
+    for (const TriGeom& t : tris)
+        for (const f3& p : t.v) {
+            mn.x = p.x < mn.x ? p.x : mn.x;
+            mn.y = p.y < mn.y ? p.y : mn.y;
+            mn.z = p.z < mn.z ? p.z : mn.z;
+            mx.x = p.x > mx.x ? p.x : mx.x;
+            mx.y = p.y > mx.y ? p.y : mx.y;
+            mx.z = p.z > mx.z ? p.z : mx.z;
+        }
+
+    HostNode root;
+    root.bmin = mn - vabs(mn * mk(aabb_eps, aabb_eps, aabb_eps));  // octree.cc:48
+    root.bmax = mx + vabs(mx * mk(aabb_eps, aabb_eps, aabb_eps));
+    root.depth = 0;
+    root.tri_begin = 0;
+    root.tri_count = (uint32_t)n;
+    out.pool.resize(n);
+    for (uint64_t i = 0; i < n; ++i) out.pool[i] = (uint32_t)i;
+    out.nodes.push_back(root);
+    if (n <= max_per_bb) {  // octree.cc:56-63
+        out.nodes[0].leaf = true;
+        out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        return true;
+    }
+
+    // The reference pops a FIFO queue (octree.cc:65-69).  All nodes of one depth leave the queue before any
+    // node of the next depth, and children are appended in (parent order, octant order), so processing one
+    // depth at a time and committing the children in that order numbers the nodes identically -- and lets
+    // the (node, octant) assignment work of a whole depth run on several host threads.
+    const unsigned workers = worker_count();
+    std::vector<uint32_t> frontier{0};
+    std::vector<Split> work;
+    while (!frontier.empty()) {
+        std::vector<uint32_t> todo;  // frontier nodes that are actually subdivided (not at max depth)
+        for (uint32_t ni : frontier) {
+            if (out.nodes[ni].depth == max_depth)
+                out.nodes[ni].leaf = true;  // octree.cc:71-74
+            else
+                todo.push_back(ni);
+        }
+        work.clear();
+        work.resize(todo.size());
+        for (size_t k = 0; k < todo.size(); ++k) {  // octree.cc:81-97
+            const HostNode& cur = out.nodes[todo[k]];
+            const f3 half = div_guard(vabs(cur.bmax - cur.bmin), 2.0f);
+            const f3 min_eps = vabs(cur.bmin) * aabb_eps;
+            const f3 max_eps = vabs(cur.bmax) * aabb_eps;
+            for (unsigned o = 0; o < 8; ++o) {
+                const f3 omin = mk(cur.bmin.x + (half.x * (float)((o & 4) >> 2)), cur.bmin.y + (half.y * (float)((o & 2) >> 1)),
+                                   cur.bmin.z + (half.z * (float)(o & 1)));
+                const f3 omax = omin + half;
+                work[k].cmin[o] = omin - min_eps;
+                work[k].cmax[o] = omax + max_eps;
+            }
+        }
+        parallel_for(todo.size() * 8, workers, [&](size_t task) {  // octree.cc:100-105
+            const size_t k = task >> 3;
+            const unsigned o = (unsigned)(task & 7);
+            const HostNode& cur = out.nodes[todo[k]];
+            std::vector<uint32_t>& dst = work[k].list[o];
+            const uint32_t* src = out.pool.data() + cur.tri_begin;
+            for (uint32_t j = 0; j < cur.tri_count; ++j) {
+                const TriGeom& t = tris[src[j]];
+                if (tri_box_overlap(t.v, t.n, work[k].cmin[o], work[k].cmax[o])) dst.push_back(src[j]);
+            }
+        });
+        std::vector<uint32_t> next;
+        std::vector<uint8_t> seen;
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const uint32_t ni = todo[k];
+            const uint32_t parent_count = out.nodes[ni].tri_count;
+            bool split = false;
+            for (unsigned o = 0; o < 8; ++o)
+                if (work[k].list[o].size() != parent_count) split = true;  // octree.cc:107-109
+            if (!split) {  // octree.cc:119-122
+                out.nodes[ni].leaf = true;
+                continue;
+            }
+            // octree.cc:124-152: every parent triangle must be in at least one octant.  The octant lists are
+            // ascending subsequences of the parent's list, so a merge-style count of distinct entries suffices.
+            {
+                const uint32_t* src = out.pool.data() + out.nodes[ni].tri_begin;
+                size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t covered = 0;
+                for (uint32_t j = 0; j < parent_count; ++j) {
+                    bool hit = false;
+                    for (unsigned o = 0; o < 8; ++o) {
+                        const auto& l = work[k].list[o];
+                        if (pos[o] < l.size() && l[pos[o]] == src[j]) {
+                            ++pos[o];
+                            hit = true;
+                        }
+                    }
+                    covered += hit;
+                }
+                if (covered != parent_count) {
+                    err = "octree build: " + std::to_string(parent_count - covered) + " of " + std::to_string(parent_count) +
+                          " parent triangles were assigned to no octant (node " + std::to_string(ni) + ")";
+                    return false;
+                }
+            }
+            for (unsigned o = 0; o < 8; ++o) {  // octree.cc:112-116, 154-164
+                const auto& l = work[k].list[o];
+                if (l.empty()) continue;
+                HostNode c;
+                c.depth = out.nodes[ni].depth + 1;
+                c.bmin = work[k].cmin[o];
+                c.bmax = work[k].cmax[o];
+                c.tri_begin = out.pool.size();
+                c.tri_count = (uint32_t)l.size();
+                out.pool.insert(out.pool.end(), l.begin(), l.end());
+                const uint32_t ci = (uint32_t)out.nodes.size();
+                if (l.size() > max_per_bb) {
+                    c.leaf = false;
+                    next.push_back(ci);
+                } else {
+                    c.leaf = true;
+                }
+                out.nodes.push_back(c);
+                out.nodes[ni].child[o] = (int32_t)ci;
+            }
+            for (auto& l : work[k].list) std::vector<uint32_t>().swap(l);
+        }
+        frontier.swap(next);
+    }
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return true;
+}
+
+void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out) {
+    out = FlatOctree();
+    if (t.empty) return;
+    const size_t nn = t.nodes.size();
+    std::vector<uint32_t> rec_of(nn, 0), slot_of(nn, 0);
+    uint32_t n_rec = 0;
+    uint64_t n_slot = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        if (t.nodes[i].leaf) {
+            slot_of[i] = (uint32_t)n_slot;
+            n_slot += t.nodes[i].tri_count;
+        } else {
+            rec_of[i] = n_rec++;
+        }
+    }
+    out.nodes.resize(n_rec);
+    out.slots.resize(n_slot);
+    uint32_t deepest_internal = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        const HostNode& n = t.nodes[i];
+        if (n.leaf) {
+            for (uint32_t k = 0; k < n.tri_count; ++k) {
+                const uint32_t ti = t.pool[n.tri_begin + k];
+                const float* p = positions + (size_t)ti * 9;
+                LeafTri& s = out.slots[slot_of[i] + k];
+                s.ax = p[0]; s.ay = p[1]; s.az = p[2];
+                s.e1x = p[3] - p[0]; s.e1y = p[4] - p[1]; s.e1z = p[5] - p[2];
+                s.e2x = p[6] - p[0]; s.e2y = p[7] - p[1]; s.e2z = p[8] - p[2];
+                s.tri = ti;
+                s.pad0 = s.pad1 = 0;
+            }
+            continue;
+        }
+        deepest_internal = std::max(deepest_internal, n.depth);
+        NodeRec& r = out.nodes[rec_of[i]];
+        std::memset(&r, 0, sizeof r);
+        for (int o = 0; o < 8; ++o) {
+            const int32_t ci = n.child[o];
+            if (ci < 0 || t.nodes[ci].tri_count == 0) continue;  // octree.cc:195
+            const HostNode& c = t.nodes[ci];
+            r.box[o][0] = c.bmin.x; r.box[o][1] = c.bmin.y; r.box[o][2] = c.bmin.z;
+            r.box[o][3] = c.bmax.x; r.box[o][4] = c.bmax.y; r.box[o][5] = c.bmax.z;
+            if (c.leaf) {
+                r.info[o][0] = slot_of[ci];
+                r.info[o][1] = c.tri_count;
+            } else {
+                r.info[o][0] = rec_of[ci];
+                r.info[o][1] = kChildInternal;
+            }
+        }
+    }
+    if (t.nodes[0].leaf) {
+        out.root_info[0] = 0;
+        out.root_info[1] = t.nodes[0].tri_count;
+        out.max_stack = 0;
+    } else {
+        out.root_info[0] = 0;
+        out.root_info[1] = kChildInternal;
+        // Depth-first traversal that pushes only internal children: after popping a node at depth d it holds at
+        // most 7 pending siblings per level above plus up to 8 fresh children.
+        out.max_stack = 7 * deepest_internal + 8;
+    }
+}
+
+TreeShape tree_shape(const HostOctree& t) {
+    TreeShape s;
+    if (t.empty) return s;
+    long long total_depth = 0, total_tris = 0;
+    for (const HostNode& n : t.nodes) {
+        s.nodes++;
+        if (n.leaf) {
+            s.leaf_refs += n.tri_count;
+            continue;
+        }
+        s.internal++;
+        for (int o = 0; o < 8; ++o) {
+            if (n.child[o] < 0) continue;
+            const HostNode& c = t.nodes[n.child[o]];
+            if (!c.leaf) continue;
+            s.leaves++;
+            s.max_depth = std::max<uint64_t>(s.max_depth, c.depth);
+            s.max_tris_in_leaf = std::max<uint64_t>(s.max_tris_in_leaf, c.tri_count);
+            total_depth += c.depth;
+            total_tris += c.tri_count;
+        }
+    }
+    s.avg_leaf_depth = (float)total_depth / (float)s.leaves;
+    s.avg_tris_in_leaf = (float)total_tris / (float)s.leaves;
+    return s;
+}
+
+}  // namespace rt

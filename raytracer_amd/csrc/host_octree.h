@@ -1,0 +1,88 @@
+// host_octree.h -- host-side octree construction and its flattening into the device layout.
+//
+// The tree is built with exactly the splitting rule of the reference's Octree::Build
+// (src/ADS/Octree/octree.cc:19-171 of the reference): same boxes, same triangle-to-octant
+// assignment (13-axis SAT, src/collision_detection.h:89-138), same leaf criteria, nodes
+// numbered in the reference's queue (breadth-first) order.  It is then flattened into two
+// arrays that the gfx950 kernels read with scalar loads:
+//
+//   NodeRec[ internal node ]  256 B: the boxes of its 8 octants + what each octant is
+//   LeafTri[ leaf slot ]       48 B: one triangle reference of one leaf, geometry inlined
+//
+// Leaf slots are laid out leaf after leaf in breadth-first leaf order, each leaf's triangles in
+// ascending triangle index.  The reference's candidate list for a ray is the concatenation of the
+// visited leaves' lists in breadth-first order (octree.cc:186-191), so the global slot index of a
+// reference is its rank in every candidate list that contains it: the smallest slot among equal
+// hit distances is the reference's winner (src/Renderer/renderer.cc:130-132).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_math.h"
+
+namespace rt {
+
+struct HostNode {
+    bool leaf = false;
+    uint32_t depth = 0;
+    f3 bmin{0, 0, 0}, bmax{0, 0, 0};
+    uint64_t tri_begin = 0;  // into HostOctree::pool
+    uint32_t tri_count = 0;
+    int32_t child[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+};
+
+struct HostOctree {
+    bool empty = true;            // no triangles: the reference leaves its root null (octree.cc:24-27)
+    std::vector<HostNode> nodes;  // breadth-first (creation) order, nodes[0] = root
+    std::vector<uint32_t> pool;   // triangle index lists of all nodes
+    double build_seconds = 0.0;
+};
+
+// Geometry of one triangle as the kernels want it: a, e1 = b - a, e2 = c - a
+// (src/collision_detection.h:21-22 computes the same two subtractions per test).
+struct alignas(16) LeafTri {
+    float ax, ay, az;
+    float e1x, e1y, e1z;
+    float e2x, e2y, e2z;
+    uint32_t tri;  // triangle index in Build order
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(LeafTri) == 48, "LeafTri must be 48 bytes");
+
+constexpr uint32_t kChildInternal = 0x80000000u;
+
+// One internal node.  info[o][1] == 0: octant o is null/empty (skipped before any box test,
+// octree.cc:195); info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0];
+// otherwise a leaf with info[o][1] triangles whose slots start at info[o][0].
+struct alignas(64) NodeRec {
+    float box[8][6];  // min xyz, max xyz of each octant's (inflated) box
+    uint32_t info[8][2];
+};
+static_assert(sizeof(NodeRec) == 256, "NodeRec must be 256 bytes");
+
+struct FlatOctree {
+    std::vector<NodeRec> nodes;  // internal nodes, breadth-first
+    std::vector<LeafTri> slots;  // leaf slots, breadth-first leaf order
+    uint32_t root_info[2] = {0, 0};  // like NodeRec::info for the root (never box-tested, octree.cc:177)
+    uint32_t max_stack = 0;          // deepest traversal stack any ray can need
+};
+
+struct TreeShape {
+    uint64_t max_depth = 0, nodes = 0, leaves = 0, max_tris_in_leaf = 0, leaf_refs = 0, internal = 0;
+    float avg_leaf_depth = 0, avg_tris_in_leaf = 0;
+};
+
+// positions: n x 9 floats.  Returns false and sets err if the reference's build invariant (every parent
+// triangle lands in at least one octant, octree.cc:124-152) is violated.
+bool build_octree(const float* positions, uint64_t n, uint32_t max_tris_per_bb, uint32_t max_depth, HostOctree& out,
+                  std::string& err);
+void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out);
+TreeShape tree_shape(const HostOctree& t);  // octree.cc:226-266
+
+// Exact host versions of the reference's primitives (used by the builder; exported for unit tests).
+bool tri_box_overlap(const f3 v[3], f3 normal, f3 bmin, f3 bmax);  // src/collision_detection.h:89-138
+f3 face_normal(const f3 v[3]);                                      // src/triangle.h:28-32
+
+}  // namespace rt

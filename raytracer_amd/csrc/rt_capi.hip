@@ -1,0 +1,784 @@
+// rt_capi.hip -- the C ABI declared in include/raytracer_amd.h: handle management, host-side
+// octree build + upload, kernel launches.  Everything below the ABI is C++/HIP for gfx950.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "host_octree.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+struct DevBuf {  // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = std::max<size_t>(n, 64);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Level {
+    DevBuf<RayRec> rays;
+    DevBuf<NodeOut> out;
+    DevBuf<float> hit_t;
+    DevBuf<int32_t> hit_tri;
+    DevBuf<uint32_t> work;
+    uint32_t n = 0;
+    hipError_t reserve(uint32_t count, bool need_rays) {
+        hipError_t e;
+        if (need_rays && (e = rays.reserve(count)) != hipSuccess) return e;
+        if ((e = out.reserve(count)) != hipSuccess) return e;
+        if ((e = hit_t.reserve(count)) != hipSuccess) return e;
+        if ((e = hit_tri.reserve(count)) != hipSuccess) return e;
+        return work.reserve(count);
+    }
+    void release() {
+        rays.release(); out.release(); hit_t.release(); hit_tri.release(); work.release();
+    }
+};
+
+constexpr int kMaxTimed = 64;
+
+}  // namespace
+
+struct rt_ads {
+    int device = 0;
+    uint32_t max_per_bb = 16, max_depth = 10;
+    bool built = false, shading_set = false, has_normals = false, branching = false;
+    uint64_t n_tri = 0;
+    std::vector<float> positions;
+    HostOctree host;
+    FlatOctree flat;
+    TreeShape shape;
+    DevBuf<NodeRec> d_nodes;
+    DevBuf<LeafTri> d_slots, d_tri_geom;
+    DevBuf<TriShade> d_tri_shade;
+    DevBuf<float> d_vnorm;
+    DevBuf<MatDev> d_mats;
+    DevBuf<LightDev> d_lights;
+    uint32_t n_lights = 0;
+    std::vector<Level> levels;
+    DevBuf<uint32_t> d_counters;  // one CNT_WORDS block per level
+    uint32_t* h_counters = nullptr;
+    DevBuf<float> d_accum, d_stage;
+    DevBuf<uint8_t> d_io;  // staging for host-memory query calls
+    hipEvent_t ev[2 + 4 * kMaxTimed] = {};
+    bool events_ready = false;
+    rt_query_stats q{};
+};
+
+namespace {
+
+DevOctree dev_tree(const rt_ads* a) {
+    DevOctree t;
+    t.nodes = a->d_nodes.p;
+    t.slots = a->d_slots.p;
+    t.root_info0 = a->flat.root_info[0];
+    t.root_info1 = a->host.empty ? 0u : a->flat.root_info[1];
+    t.n_nodes = (uint32_t)a->flat.nodes.size();
+    t.n_slots = (uint32_t)a->flat.slots.size();
+    return t;
+}
+
+int use_device(const rt_ads* a) {
+    HIP_TRY(hipSetDevice(a->device));
+    return RT_OK;
+}
+
+bool tri_equal(const float* pa, const float* na, const float* pb, const float* nb) {
+    // src/triangle.h:15-19 with src/vertex.h:12 and src/vec3.h:32
+    auto veq = [&](int i, int j) {
+        const f3 p0 = mk(pa[i * 3], pa[i * 3 + 1], pa[i * 3 + 2]), p1 = mk(pb[j * 3], pb[j * 3 + 1], pb[j * 3 + 2]);
+        f3 n0 = mk(0, 0, 0), n1 = mk(0, 0, 0);
+        if (na) n0 = mk(na[i * 3], na[i * 3 + 1], na[i * 3 + 2]);
+        if (nb) n1 = mk(nb[j * 3], nb[j * 3 + 1], nb[j * 3 + 2]);
+        return eq_eps(p0, p1) && eq_eps(n0, n1);
+    };
+    return (veq(0, 0) && veq(1, 1) && veq(2, 2)) || (veq(0, 1) && veq(1, 2) && veq(2, 0)) || (veq(0, 2) && veq(1, 0) && veq(2, 1));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err; }
+const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950, wave64 packet octree traversal)"; }
+
+uint32_t rt_rng_u31(uint32_t seed, uint32_t pixel, uint32_t spp_sample, uint32_t node_id, uint32_t light, uint32_t sample,
+                    uint32_t dim) {
+    return rng_finish(rng_prefix(seed, pixel, spp_sample, node_id), light, sample, dim);
+}
+
+int rt_ads_kind_from_name(const char* name, int* out_kind) {
+    if (!name || !out_kind) return fail(RT_ERR_INVALID, "null argument");
+    if (!strcmp(name, "none")) *out_kind = RT_ADS_NONE;
+    else if (!strcmp(name, "octree")) *out_kind = RT_ADS_OCTREE;
+    else if (!strcmp(name, "octee_parametric")) *out_kind = RT_ADS_OCTREE_PARAMETRIC;  // the reference's spelling
+    else if (!strcmp(name, "octree_gpu")) *out_kind = RT_ADS_OCTREE_GPU;
+    else return fail(RT_ERR_INVALID, "Invalid data structure");
+    return RT_OK;
+}
+
+}  // extern "C"
+
+struct rt_host_tree {
+    HostOctree host;
+    FlatOctree flat;
+};
+
+extern "C" {
+
+int rt_host_tree_build(const float* positions, uint64_t n, uint32_t max_per_bb, uint32_t max_depth, rt_host_tree** out) {
+    if ((!positions && n) || !out) return fail(RT_ERR_INVALID, "null argument");
+    rt_host_tree* t = new rt_host_tree();
+    std::string err;
+    if (!build_octree(positions, n, max_per_bb, max_depth, t->host, err)) {
+        delete t;
+        return fail(RT_ERR_BUILD, "%s", err.c_str());
+    }
+    flatten_octree(t->host, positions, t->flat);
+    *out = t;
+    return RT_OK;
+}
+void rt_host_tree_destroy(rt_host_tree* t) { delete t; }
+int rt_host_tree_sizes(const rt_host_tree* t, uint64_t* n_nodes, uint64_t* n_pool, uint64_t* n_records, uint64_t* n_slots,
+                       uint32_t* max_stack) {
+    if (!t) return fail(RT_ERR_INVALID, "null argument");
+    if (n_nodes) *n_nodes = t->host.nodes.size();
+    if (n_pool) *n_pool = t->host.pool.size();
+    if (n_records) *n_records = t->flat.nodes.size();
+    if (n_slots) *n_slots = t->flat.slots.size();
+    if (max_stack) *max_stack = t->flat.max_stack;
+    return RT_OK;
+}
+int rt_host_tree_export(const rt_host_tree* t, uint8_t* is_leaf, uint32_t* depth, float* bmin, float* bmax, int32_t* child8,
+                        uint64_t* tri_begin, uint32_t* tri_count, uint32_t* pool) {
+    if (!t) return fail(RT_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < t->host.nodes.size(); ++i) {
+        const HostNode& n = t->host.nodes[i];
+        if (is_leaf) is_leaf[i] = n.leaf;
+        if (depth) depth[i] = n.depth;
+        if (bmin) { bmin[i * 3] = n.bmin.x; bmin[i * 3 + 1] = n.bmin.y; bmin[i * 3 + 2] = n.bmin.z; }
+        if (bmax) { bmax[i * 3] = n.bmax.x; bmax[i * 3 + 1] = n.bmax.y; bmax[i * 3 + 2] = n.bmax.z; }
+        if (child8) for (int o = 0; o < 8; ++o) child8[i * 8 + o] = n.child[o];
+        if (tri_begin) tri_begin[i] = n.tri_begin;
+        if (tri_count) tri_count[i] = n.tri_count;
+    }
+    if (pool && !t->host.pool.empty()) memcpy(pool, t->host.pool.data(), t->host.pool.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info2) {
+    if (!t) return fail(RT_ERR_INVALID, "null argument");
+    if (node_records && !t->flat.nodes.empty()) memcpy(node_records, t->flat.nodes.data(), t->flat.nodes.size() * sizeof(NodeRec));
+    if (leaf_slots && !t->flat.slots.empty()) memcpy(leaf_slots, t->flat.slots.data(), t->flat.slots.size() * sizeof(LeafTri));
+    if (root_info2) {
+        root_info2[0] = t->flat.root_info[0];
+        root_info2[1] = t->host.empty ? 0u : t->flat.root_info[1];
+    }
+    return RT_OK;
+}
+int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out) {
+    if (!t || !out) return fail(RT_ERR_INVALID, "null argument");
+    const TreeShape s = tree_shape(t->host);
+    memset(out, 0, sizeof *out);
+    out->max_depth = s.max_depth; out->nodes = s.nodes; out->leaves = s.leaves; out->max_triangles_in_leaf = s.max_tris_in_leaf;
+    out->avg_leaf_depth = s.avg_leaf_depth; out->avg_triangles_in_leaf = s.avg_tris_in_leaf; out->leaf_refs = s.leaf_refs;
+    out->internal_nodes = s.internal; out->build_seconds = t->host.build_seconds;
+    out->device_bytes = t->flat.nodes.size() * sizeof(NodeRec) + t->flat.slots.size() * sizeof(LeafTri);
+    return RT_OK;
+}
+
+int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
+    if (!cfg || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (cfg->struct_size != sizeof(rt_ads_config)) return fail(RT_ERR_INVALID, "rt_ads_config.struct_size mismatch");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (cfg->device < 0 || cfg->device >= count) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", cfg->device, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (prop.warpSize != 64) return fail(RT_ERR_UNSUPPORTED, "device %d is not a wave64 device", cfg->device);
+    rt_ads* a = new rt_ads();
+    a->device = cfg->device;
+    a->max_per_bb = cfg->max_triangles_per_bb;
+    a->max_depth = cfg->max_depth;
+    *out = a;
+    return RT_OK;
+}
+
+void rt_ads_destroy(rt_ads* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
+    a->d_mats.release(); a->d_lights.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
+    for (auto& l : a->levels) l.release();
+    if (a->h_counters) (void)hipHostFree(a->h_counters);
+    if (a->events_ready)
+        for (auto& e : a->ev) (void)hipEventDestroy(e);
+    delete a;
+}
+
+int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
+    if (!a || (!positions && n)) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 triangles");
+    if (int rc = use_device(a)) return rc;
+    a->built = false;
+    a->shading_set = false;
+    a->n_tri = n;
+    a->positions.assign(positions, positions + n * 9);
+    std::string err;
+    if (!build_octree(a->positions.data(), n, a->max_per_bb, a->max_depth, a->host, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
+    flatten_octree(a->host, a->positions.data(), a->flat);
+    if (a->flat.max_stack > 128)
+        return fail(RT_ERR_UNSUPPORTED, "octree too deep for the register-resident traversal stack (%u > 128 entries)", a->flat.max_stack);
+    if (a->flat.slots.size() > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");
+    a->shape = tree_shape(a->host);
+    HIP_TRY(a->d_nodes.reserve(a->flat.nodes.size()));
+    HIP_TRY(a->d_slots.reserve(a->flat.slots.size()));
+    HIP_TRY(a->d_tri_geom.reserve(n));
+    if (!a->flat.nodes.empty())
+        HIP_TRY(hipMemcpy(a->d_nodes.p, a->flat.nodes.data(), a->flat.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    if (!a->flat.slots.empty())
+        HIP_TRY(hipMemcpy(a->d_slots.p, a->flat.slots.data(), a->flat.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    if (n) {
+        std::vector<LeafTri> g(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            const float* p = a->positions.data() + i * 9;
+            LeafTri& s = g[i];
+            s.ax = p[0]; s.ay = p[1]; s.az = p[2];
+            s.e1x = p[3] - p[0]; s.e1y = p[4] - p[1]; s.e1z = p[5] - p[2];
+            s.e2x = p[6] - p[0]; s.e2y = p[7] - p[1]; s.e2z = p[8] - p[2];
+            s.tri = (uint32_t)i;
+            s.pad0 = s.pad1 = 0;
+        }
+        HIP_TRY(hipMemcpy(a->d_tri_geom.p, g.data(), n * sizeof(LeafTri), hipMemcpyHostToDevice));
+    }
+    if (!a->h_counters) HIP_TRY(hipHostMalloc((void**)&a->h_counters, 64 * CNT_WORDS * sizeof(uint32_t)));
+    a->built = true;
+    return RT_OK;
+}
+
+int rt_ads_tree_stats(const rt_ads* a, rt_tree_stats* out) {
+    if (!a || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    memset(out, 0, sizeof *out);
+    out->max_depth = a->shape.max_depth;
+    out->nodes = a->shape.nodes;
+    out->leaves = a->shape.leaves;
+    out->max_triangles_in_leaf = a->shape.max_tris_in_leaf;
+    out->avg_leaf_depth = a->shape.avg_leaf_depth;
+    out->avg_triangles_in_leaf = a->shape.avg_tris_in_leaf;
+    out->leaf_refs = a->shape.leaf_refs;
+    out->internal_nodes = a->shape.internal;
+    out->build_seconds = a->host.build_seconds;
+    out->device_bytes = a->flat.nodes.size() * sizeof(NodeRec) + a->flat.slots.size() * sizeof(LeafTri) + a->n_tri * sizeof(LeafTri);
+    return RT_OK;
+}
+
+int rt_ads_query_stats(const rt_ads* a, rt_query_stats* out) {
+    if (!a || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = a->q;
+    return RT_OK;
+}
+int rt_ads_reset_query_stats(rt_ads* a) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    a->q = rt_query_stats{};
+    return RT_OK;
+}
+
+int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap, uint64_t* out_total) {
+    if (!a || (!rays && n) || !out_offsets || !out_total) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (int rc = use_device(a)) return rc;
+    out_offsets[0] = 0;
+    *out_total = 0;
+    if (n == 0) return RT_OK;
+    if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
+    // A ray can enqueue every node once; chunk the batch so that the queues fit a bounded workspace.
+    const uint64_t queue_cap = std::max<uint64_t>(a->host.nodes.size(), 1);
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / (queue_cap * 8)));
+    DevBuf<float> d_rays;
+    DevBuf<uint32_t> d_queue, d_out;
+    DevBuf<uint64_t> d_counts, d_offs;
+    auto cleanup = [&] { d_rays.release(); d_queue.release(); d_out.release(); d_counts.release(); d_offs.release(); };
+    std::vector<uint64_t> counts(n);
+    const DevOctree T = dev_tree(a);
+    hipError_t e;
+#define SEARCH_TRY(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
+    SEARCH_TRY(d_rays.reserve(chunk * 6));
+    SEARCH_TRY(d_queue.reserve(chunk * queue_cap * 2));
+    SEARCH_TRY(d_counts.reserve(chunk));
+    SEARCH_TRY(d_offs.reserve(chunk));
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            uint64_t total = 0;
+            for (uint64_t i = 0; i < n; ++i) {
+                out_offsets[i] = total;
+                total += counts[i];
+            }
+            out_offsets[n] = total;
+            *out_total = total;
+            if (total > cap || (!out_tri && total)) { cleanup(); return fail(RT_ERR_CAPACITY, "candidate buffer too small: need %llu entries", (unsigned long long)total); }
+        }
+        for (uint64_t b = 0; b < n; b += chunk) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
+            SEARCH_TRY(hipMemcpy(d_rays.p, rays + b * 6, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice));
+            const dim3 grid((m + 63) / 64), block(64);
+            if (pass == 0) {
+                hipLaunchKernelGGL(k_search<false>, grid, block, 0, 0, T, d_rays.p, m, d_queue.p, (uint32_t)queue_cap, d_counts.p, nullptr, nullptr);
+                SEARCH_TRY(hipGetLastError());
+                SEARCH_TRY(hipMemcpy(counts.data() + b, d_counts.p, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < m; ++i)
+                    if (counts[b + i] == ~0ull) { cleanup(); return fail(RT_ERR_HIP, "search queue overflow"); }
+            } else {
+                std::vector<uint64_t> rel(m);
+                const uint64_t base = out_offsets[b];
+                for (uint32_t i = 0; i < m; ++i) rel[i] = out_offsets[b + i] - base;
+                const uint64_t chunk_total = out_offsets[b + m] - base;
+                if (chunk_total == 0) continue;
+                SEARCH_TRY(d_out.reserve(chunk_total));
+                SEARCH_TRY(hipMemcpy(d_offs.p, rel.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_search<true>, grid, block, 0, 0, T, d_rays.p, m, d_queue.p, (uint32_t)queue_cap, nullptr, d_offs.p, d_out.p);
+                SEARCH_TRY(hipGetLastError());
+                SEARCH_TRY(hipMemcpy(out_tri + base, d_out.p, chunk_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+        }
+    }
+#undef SEARCH_TRY
+    cleanup();
+    a->q.search_calls += n;
+    return RT_OK;
+}
+
+int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uint64_t n, int cull, int mem, float* out_t,
+                         int32_t* out_tri, void* stream_) {
+    if (!a || ((!origins || !dirs || !out_t || !out_tri) && n)) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (n > 0xffffffffull * 64) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
+    if (int rc = use_device(a)) return rc;
+    if (n == 0) return RT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float *d_o = origins, *d_d = dirs;
+    float* d_t = out_t;
+    int32_t* d_tri = out_tri;
+    if (mem == RT_MEM_HOST) {
+        const size_t b3 = n * 3 * sizeof(float), b1 = n * sizeof(float);
+        HIP_TRY(a->d_io.reserve(2 * b3 + 2 * b1));
+        uint8_t* p = a->d_io.p;
+        HIP_TRY(hipMemcpyAsync(p, origins, b3, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(p + b3, dirs, b3, hipMemcpyHostToDevice, stream));
+        d_o = (const float*)p;
+        d_d = (const float*)(p + b3);
+        d_t = (float*)(p + 2 * b3);
+        d_tri = (int32_t*)(p + 2 * b3 + b1);
+    } else if (mem != RT_MEM_DEVICE) {
+        return fail(RT_ERR_INVALID, "bad mem argument");
+    }
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(k_trace_closest, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, cull, d_t, d_tri);
+    HIP_TRY(hipGetLastError());
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(out_tri, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    a->q.search_calls += n;
+    a->q.closest_rays += n;
+    return RT_OK;
+}
+
+int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64_t n, int cull, int mem, uint8_t* out, void* stream_) {
+    if (!a || ((!points || !lights || !out) && n)) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (n > 0xffffffffull * 64) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
+    if (int rc = use_device(a)) return rc;
+    if (n == 0) return RT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float *d_p = points, *d_l = lights;
+    uint8_t* d_out = out;
+    if (mem == RT_MEM_HOST) {
+        const size_t b3 = n * 3 * sizeof(float);
+        HIP_TRY(a->d_io.reserve(2 * b3 + n));
+        uint8_t* p = a->d_io.p;
+        HIP_TRY(hipMemcpyAsync(p, points, b3, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(p + b3, lights, b3, hipMemcpyHostToDevice, stream));
+        d_p = (const float*)p;
+        d_l = (const float*)(p + b3);
+        d_out = p + 2 * b3;
+    } else if (mem != RT_MEM_DEVICE) {
+        return fail(RT_ERR_INVALID, "bad mem argument");
+    }
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(k_trace_any, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, cull, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    a->q.search_calls += n;
+    a->q.any_rays += n;
+    return RT_OK;
+}
+
+int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* material_ids, const float* materials, uint32_t n_mat) {
+    if (!a || !material_ids || !materials) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (int rc = use_device(a)) return rc;
+    const uint64_t n = a->n_tri;
+    for (uint64_t i = 0; i < n; ++i)
+        if (material_ids[i] < 0 || (uint32_t)material_ids[i] >= n_mat)
+            return fail(RT_ERR_INVALID, "triangle %llu has material id %d outside [0,%u)", (unsigned long long)i, material_ids[i], n_mat);
+    std::vector<MatDev> mats(std::max<uint32_t>(n_mat, 1));
+    a->branching = false;
+    for (uint32_t m = 0; m < n_mat; ++m) {
+        const float* f = materials + (size_t)m * 18;
+        MatDev& d = mats[m];
+        for (int k = 0; k < 3; ++k) {
+            d.diffuse[k] = f[3 + k];
+            d.specular[k] = f[6 + k];
+            d.transmittance[k] = f[9 + k];
+            d.emission[k] = f[12 + k];
+        }
+        d.shininess = f[15];
+        d.ior = f[16];
+        d.has_specular = !eq_eps(mk(f[6], f[7], f[8]), mk(0, 0, 0));        // renderer.cc:179
+        d.has_transmittance = !eq_eps(mk(f[9], f[10], f[11]), mk(0, 0, 0)); // renderer.cc:185
+        if (d.has_specular && d.has_transmittance) a->branching = true;
+    }
+    // light list: emissive triangles in Build order (obj_loader.cc:188-191)
+    std::vector<uint32_t> light_tri;
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* f = materials + (size_t)material_ids[i] * 18;
+        if (f[12] != 0.0 || f[13] != 0.0 || f[14] != 0.0) light_tri.push_back((uint32_t)i);
+    }
+    std::vector<LightDev> lights(std::max<size_t>(light_tri.size(), 1));
+    for (size_t l = 0; l < light_tri.size(); ++l) {
+        const float* p = a->positions.data() + (size_t)light_tri[l] * 9;
+        const f3 v[3] = {mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), mk(p[6], p[7], p[8])};
+        LightDev& L = lights[l];
+        const f3 e1 = v[1] - v[0], e2 = v[2] - v[0], nn = face_normal(v);
+        L.a[0] = v[0].x; L.a[1] = v[0].y; L.a[2] = v[0].z;
+        L.e1[0] = e1.x; L.e1[1] = e1.y; L.e1[2] = e1.z;
+        L.e2[0] = e2.x; L.e2[1] = e2.y; L.e2[2] = e2.z;
+        L.n[0] = nn.x; L.n[1] = nn.y; L.n[2] = nn.z;
+        L.area = 0.5f * length(cross(v[1] - v[0], v[2] - v[1]));  // src/triangle.h:34-40
+        const float* f = materials + (size_t)material_ids[light_tri[l]] * 18;
+        L.emission[0] = f[12]; L.emission[1] = f[13]; L.emission[2] = f[14];
+    }
+    std::vector<TriShade> ts(std::max<uint64_t>(n, 1));
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* p = a->positions.data() + i * 9;
+        const f3 v[3] = {mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), mk(p[6], p[7], p[8])};
+        const f3 nn = face_normal(v);
+        TriShade& t = ts[i];
+        t.nx = nn.x; t.ny = nn.y; t.nz = nn.z;
+        t.mat = material_ids[i];
+        t.light_eq = -1;
+        t.pad[0] = t.pad[1] = t.pad[2] = 0;
+        for (size_t l = 0; l < light_tri.size(); ++l) {
+            const uint32_t lt = light_tri[l];
+            if (tri_equal(a->positions.data() + (size_t)lt * 9, normals ? normals + (size_t)lt * 9 : nullptr, p, normals ? normals + i * 9 : nullptr)) {
+                t.light_eq = (int32_t)l;
+                break;
+            }
+        }
+    }
+    HIP_TRY(a->d_mats.reserve(mats.size()));
+    HIP_TRY(hipMemcpy(a->d_mats.p, mats.data(), mats.size() * sizeof(MatDev), hipMemcpyHostToDevice));
+    HIP_TRY(a->d_lights.reserve(lights.size()));
+    HIP_TRY(hipMemcpy(a->d_lights.p, lights.data(), lights.size() * sizeof(LightDev), hipMemcpyHostToDevice));
+    HIP_TRY(a->d_tri_shade.reserve(ts.size()));
+    HIP_TRY(hipMemcpy(a->d_tri_shade.p, ts.data(), ts.size() * sizeof(TriShade), hipMemcpyHostToDevice));
+    a->has_normals = normals != nullptr;
+    if (normals && n) {
+        HIP_TRY(a->d_vnorm.reserve(n * 9));
+        HIP_TRY(hipMemcpy(a->d_vnorm.p, normals, n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    a->n_lights = (uint32_t)light_tri.size();
+    a->shading_set = true;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Camera frame, src/Renderer/renderer.cc:82-96.  tanf runs on the host (same libm call as the reference).
+int frame_params(const rt_ads* a, const rt_render_config* c, FrameParams& F, uint32_t& n0) {
+    if (c->struct_size != sizeof(rt_render_config)) return fail(RT_ERR_INVALID, "rt_render_config.struct_size mismatch");
+    if (c->width < 1 || c->height < 1) return fail(RT_ERR_INVALID, "image size must be positive");
+    if (c->samples_per_pixel < 1) return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1 (renderer.cc:43 would wrap)");
+    if (c->render_type < 0 || c->render_type > 3) return fail(RT_ERR_INVALID, "Invalid render type");
+    if (c->shading_type < 0 || c->shading_type > 1) return fail(RT_ERR_INVALID, "Invalid shading type");
+    if (c->shading_type == RT_SHADING_SMOOTH && !a->has_normals) return fail(RT_ERR_INVALID, "smooth shading needs vertex normals");
+    if (c->band_world < 1 || c->band_rank < 0 || c->band_rank >= c->band_world) return fail(RT_ERR_INVALID, "bad band_rank/band_world");
+    if (c->max_depth < 0 || c->max_depth > 30) return fail(RT_ERR_INVALID, "renderer max_depth must be in [0,30]");
+    if ((uint64_t)c->width * (uint64_t)c->height > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "image too large");
+    const f3 dir = mk(c->cam_dir[0], c->cam_dir[1], c->cam_dir[2]), up = mk(c->cam_up[0], c->cam_up[1], c->cam_up[2]);
+    const float t = 1.0f;
+    const f3 b = cross(dir, up);
+    const float gw = 2 * t * tanf(c->fov / 2.0f);
+    const float gh = c->aspect_mode == RT_ASPECT_TRUE ? gw * ((float)c->height / (float)c->width) : gw * (float)(c->height / c->width);
+    F.qw = b * (gw / (float)(c->width - 1));
+    F.qh = up * (gh / (float)(c->height - 1));
+    F.p00 = ((dir * t) - (b * (gw / 2))) + (up * (gh / 2));
+    F.cam_pos = mk(c->cam_pos[0], c->cam_pos[1], c->cam_pos[2]);
+    F.bg = mk(c->background[0], c->background[1], c->background[2]);
+    F.width = c->width;
+    F.height = c->height;
+    F.tiles_x = (c->width + 7) / 8;
+    F.band_rank = c->band_rank;
+    F.band_world = c->band_world;
+    F.render_type = c->render_type;
+    F.shading_type = c->shading_type;
+    F.cull = c->cull_backfaces;
+    F.max_depth = c->max_depth;
+    F.spt = c->samples_per_triangle;
+    F.max_distance = c->max_distance;
+    F.seed = c->seed;
+    F.spp_sample = 0;
+    F.spp = c->samples_per_pixel;
+    const int bands = (c->height + 7) / 8;
+    const int local_bands = bands > c->band_rank ? (bands - c->band_rank + c->band_world - 1) / c->band_world : 0;
+    const uint64_t nodes = (uint64_t)local_bands * (uint64_t)F.tiles_x * 64ull;
+    if (nodes > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "image too large");
+    n0 = (uint32_t)nodes;
+    return RT_OK;
+}
+
+SceneDev scene_dev(const rt_ads* a) {
+    SceneDev S;
+    S.tree = dev_tree(a);
+    S.tri_geom = a->d_tri_geom.p;
+    S.tri_shade = a->d_tri_shade.p;
+    S.tri_vnorm = a->d_vnorm.p;
+    S.mats = a->d_mats.p;
+    S.lights = a->d_lights.p;
+    S.n_lights = a->n_lights;
+    return S;
+}
+
+int ensure_events(rt_ads* a) {
+    if (a->events_ready) return RT_OK;
+    for (auto& e : a->ev) HIP_TRY(hipEventCreate(&e));
+    a->events_ready = true;
+    return RT_OK;
+}
+
+int read_counters(rt_ads* a, uint32_t level, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(a->h_counters, a->d_counters.p + (size_t)level * CNT_WORDS, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_render_stats* stats, void* stream_) {
+    if (!a || !c || !out_rgb) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    if (mem != RT_MEM_HOST && mem != RT_MEM_DEVICE) return fail(RT_ERR_INVALID, "bad mem argument");
+    if (int rc = use_device(a)) return rc;
+    FrameParams F;
+    uint32_t n0 = 0;
+    if (int rc = frame_params(a, c, F, n0)) return rc;
+    if (int rc = ensure_events(a)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const SceneDev S = scene_dev(a);
+    const uint32_t max_levels = (uint32_t)c->max_depth + 1;
+    if (a->levels.size() < max_levels) a->levels.resize(max_levels);
+    HIP_TRY(a->d_counters.reserve((size_t)max_levels * CNT_WORDS));
+    const size_t frame_floats = (size_t)c->width * c->height * 3;
+    float* d_out = out_rgb;
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(a->d_stage.reserve(frame_floats));
+        d_out = a->d_stage.p;
+    }
+    if (c->samples_per_pixel > 1) { HIP_TRY(a->d_accum.reserve((size_t)n0 * 3)); }
+
+    rt_render_stats st{};
+    int n_timed_closest = 0, n_timed_shade = 0;
+    hipEvent_t* ev_total = a->ev;
+    hipEvent_t* ev_closest = a->ev + 2;
+    hipEvent_t* ev_shade = a->ev + 2 + 2 * kMaxTimed;
+    HIP_TRY(hipEventRecord(ev_total[0], stream));
+    const dim3 block(256);
+    for (int s = 0; s < c->samples_per_pixel && n0 > 0; ++s) {
+        F.spp_sample = (uint32_t)s;
+        HIP_TRY(hipMemsetAsync(a->d_counters.p, 0, (size_t)max_levels * CNT_WORDS * sizeof(uint32_t), stream));
+        uint32_t n = n0, levels = 0;
+        for (uint32_t L = 0; L < max_levels && n > 0; ++L) {
+            Level& lv = a->levels[L];
+            HIP_TRY(lv.reserve(n, L > 0));
+            lv.n = n;
+            uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
+            const dim3 grid((n + 255) / 256);
+            const bool timed_c = n_timed_closest < kMaxTimed;
+            if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
+            hipLaunchKernelGGL(k_closest, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
+            HIP_TRY(hipGetLastError());
+            if (timed_c) {
+                HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream));
+                ++n_timed_closest;
+            }
+            st.launches_closest++;
+            if (L == 0) st.primary_rays += 0;  // counted below from the valid pixel count
+            else st.secondary_rays += n;
+            levels = L + 1;
+            if (int rc = read_counters(a, L, stream)) return rc;
+            const uint32_t n_work = a->h_counters[CNT_WORK];
+            if (n_work == 0) break;
+            RayRec* next_rays = nullptr;
+            uint32_t next_cap = 0;
+            if (L + 1 < max_levels) {
+                const uint64_t want = (uint64_t)n_work * (a->branching ? 2ull : 1ull);
+                if (want > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "recursion level too large");
+                HIP_TRY(a->levels[L + 1].reserve((uint32_t)want, true));
+                next_rays = a->levels[L + 1].rays.p;
+                next_cap = (uint32_t)want;
+            }
+            const dim3 grid_s((n_work + 255) / 256);
+            const bool timed_s = n_timed_shade < kMaxTimed;
+            if (timed_s) { HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade], stream)); }
+            hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.out.p, next_rays,
+                               next_cap, cnt);
+            HIP_TRY(hipGetLastError());
+            if (timed_s) {
+                HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade + 1], stream));
+                ++n_timed_shade;
+            }
+            st.launches_shade++;
+            if (int rc = read_counters(a, L, stream)) return rc;
+            st.shadow_rays += (uint64_t)a->h_counters[CNT_SHADOW_LO] | ((uint64_t)a->h_counters[CNT_SHADOW_HI] << 32);
+            n = a->h_counters[CNT_NEXT];
+            if (n > next_cap) return fail(RT_ERR_HIP, "internal: recursion queue overflow (%u > %u)", n, next_cap);
+        }
+        st.levels = std::max(st.levels, levels);
+        for (uint32_t L = levels; L-- > 1;) {
+            Level& lv = a->levels[L];
+            hipLaunchKernelGGL(k_resolve, dim3((lv.n + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, lv.n, a->levels[L - 1].out.p);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, a->levels[0].out.p, n0, a->d_accum.p, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev_total[1], stream));
+    // valid pixels of this call's bands
+    {
+        const int bands = (c->height + 7) / 8;
+        uint64_t rows = 0;
+        for (int b = c->band_rank; b < bands; b += c->band_world) rows += (uint64_t)std::min(8, c->height - b * 8);
+        st.primary_rays = rows * (uint64_t)c->width * (uint64_t)c->samples_per_pixel;
+    }
+    if (mem == RT_MEM_HOST) {
+        const int bands = (c->height + 7) / 8;
+        for (int b = c->band_rank; b < bands; b += c->band_world) {
+            const size_t row0 = (size_t)b * 8, rows = (size_t)std::min(8, c->height - b * 8);
+            const size_t off = row0 * c->width * 3, cnt = rows * c->width * 3;
+            HIP_TRY(hipMemcpyAsync(out_rgb + off, d_out + off, cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_total[0], ev_total[1]));
+    st.ms_total = ms;
+    for (int k = 0; k < n_timed_closest; ++k) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev_closest[2 * k], ev_closest[2 * k + 1]));
+        st.ms_closest += ms;
+    }
+    for (int k = 0; k < n_timed_shade; ++k) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev_shade[2 * k], ev_shade[2 * k + 1]));
+        st.ms_shade += ms;
+    }
+    st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
+    a->q.search_calls += st.rays;
+    a->q.closest_rays += st.primary_rays + st.secondary_rays;
+    a->q.any_rays += st.shadow_rays;
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, int32_t* out_tri, int mem, void* stream_) {
+    if (!a || !c || !out_t || !out_tri) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    if (mem != RT_MEM_HOST && mem != RT_MEM_DEVICE) return fail(RT_ERR_INVALID, "bad mem argument");
+    if (int rc = use_device(a)) return rc;
+    FrameParams F;
+    uint32_t n0 = 0;
+    if (int rc = frame_params(a, c, F, n0)) return rc;
+    if (c->band_world != 1) return fail(RT_ERR_UNSUPPORTED, "rt_render_primary_hits renders the whole image");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (a->levels.empty()) a->levels.resize(1);
+    Level& lv = a->levels[0];
+    HIP_TRY(lv.reserve(n0, false));
+    HIP_TRY(a->d_counters.reserve(CNT_WORDS));
+    HIP_TRY(hipMemsetAsync(a->d_counters.p, 0, CNT_WORDS * sizeof(uint32_t), stream));
+    const size_t npix = (size_t)c->width * c->height;
+    float* d_t = out_t;
+    int32_t* d_tri = out_tri;
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(a->d_io.reserve(npix * 8));
+        d_t = (float*)a->d_io.p;
+        d_tri = (int32_t*)(a->d_io.p + npix * 4);
+    }
+    const dim3 block(256), grid((n0 + 255) / 256);
+    hipLaunchKernelGGL(k_closest, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+                       lv.work.p, a->d_counters.p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
+    HIP_TRY(hipGetLastError());
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_t, d_t, npix * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(out_tri, d_tri, npix * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    const uint64_t rays = npix;
+    a->q.search_calls += rays;
+    a->q.closest_rays += rays;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+// rt_kernels.h -- gfx950 kernels of the ray-scene query path (device code, included by rt_capi.hip).
+//
+// Kernel classes
+//   k_trace_closest / k_trace_any : batched Search + closest-hit / any-hit loops for caller-supplied rays
+//   k_closest                     : one recursion level of the renderer: ray generation (level 0) or queue
+//                                   read, Search + closest hit, compaction of the hits into a work list
+//   k_shade                       : per hit: local illumination with area-light shadow samples (any-hit
+//                                   traversals), recursion gate, reflection / refraction ray construction
+//   k_resolve / k_resolve_pixels  : bottom-up evaluation of the recursion tree in the reference's order
+//   k_search_count / k_search_fill: Ads::Search restated (breadth-first candidate lists)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_traverse.h"
+
+namespace rt {
+
+struct alignas(16) TriShade {  // per triangle in Build order
+    float nx, ny, nz;          // face normal (src/triangle.h:28-32)
+    int32_t mat;               // Triangle::material_id
+    int32_t light_eq;          // first light l with lights[l] == triangle (src/triangle.h:15-19), else -1
+    int32_t pad[3];
+};
+static_assert(sizeof(TriShade) == 32, "");
+
+struct alignas(16) MatDev {  // src/material.h:7-16, plus the two epsilon-compare results of renderer.cc:179,185
+    float diffuse[3], specular[3], transmittance[3], emission[3];
+    float shininess, ior;
+    uint32_t has_specular, has_transmittance;
+};
+static_assert(sizeof(MatDev) == 64, "");
+
+struct alignas(16) LightDev {  // one emissive triangle (obj_loader.cc:188-191)
+    float a[3], e1[3], e2[3];  // vertex a, b - a, c - a (src/triangle.h:47-51)
+    float n[3];                // its face normal
+    float area;                // src/triangle.h:34-40
+    float emission[3];
+};
+static_assert(sizeof(LightDev) == 64, "");
+
+struct alignas(16) RayRec {  // one node of the recursion tree waiting to be traced
+    float o[3], d[3];
+    uint32_t parent;   // index of the parent node in the previous level
+    uint32_t pixel;    // global pixel index (key of the random generator)
+    uint32_t node_id;  // 1 = camera ray, 2n = reflection child of n, 2n+1 = refraction child of n
+    uint32_t pad[3];
+};
+static_assert(sizeof(RayRec) == 48, "");
+
+struct alignas(16) NodeOut {  // what ray_color (renderer.cc:114-195) knows about one node
+    float c[3];               // clamped local colour (renderer.cc:170), or the background on a miss
+    float fR[3], fT[3];       // material.specular / material.transmittance
+    float IR[3], IT[3];       // colours returned by the children, filled in by k_resolve
+    uint32_t flags;           // bit0: has reflection child, bit1: has refraction child
+};
+static_assert(sizeof(NodeOut) == 64, "");
+
+struct SceneDev {
+    DevOctree tree;
+    const LeafTri* tri_geom;   // per triangle in Build order: a, b-a, c-a
+    const TriShade* tri_shade;
+    const float* tri_vnorm;    // 9 floats per triangle (vertex normals) or nullptr
+    const MatDev* mats;
+    const LightDev* lights;
+    uint32_t n_lights;
+};
+
+struct FrameParams {
+    f3 cam_pos, p00, qw, qh, bg;
+    int32_t width, height, tiles_x;
+    int32_t band_rank, band_world;
+    int32_t render_type, shading_type, cull;
+    int32_t max_depth, spt;
+    float max_distance;
+    uint32_t seed, spp_sample;
+    int32_t spp;
+};
+
+enum { CNT_WORK = 0, CNT_NEXT = 1, CNT_SHADOW_LO = 2, CNT_SHADOW_HI = 3, CNT_WORDS = 4 };
+
+// ---- helpers ---------------------------------------------------------------------------------------------------
+
+// Level-0 node index -> pixel.  64 consecutive nodes are one 8x8 pixel tile = one wavefront.
+__device__ __forceinline__ bool node0_pixel(const FrameParams& F, uint32_t node, int& x, int& y) {
+    const uint32_t tile = node >> 6, lane = node & 63;
+    const uint32_t local_band = tile / (uint32_t)F.tiles_x, tx = tile % (uint32_t)F.tiles_x;
+    const uint32_t band = local_band * (uint32_t)F.band_world + (uint32_t)F.band_rank;
+    x = (int)(tx * 8 + (lane & 7));
+    y = (int)(band * 8 + (lane >> 3));
+    return x < F.width && y < F.height;
+}
+
+// src/Renderer/renderer.cc:104-106 (+ :44-46 for the jittered samples of fuzzysampling).
+__device__ __forceinline__ f3 primary_dir(const FrameParams& F, int x, int y, uint32_t pixel) {
+    const f3 pxy = (F.p00 + (F.qw * (float)x)) - (F.qh * (float)y);
+    f3 dir = div_guard(pxy, length(pxy));
+    if (F.spp_sample > 0) {
+        const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, 0);
+        const float xj = u31_to_float(rng_finish(pre, 0, 0, 0)) * 0.001f;
+        const float yj = u31_to_float(rng_finish(pre, 0, 0, 1)) * 0.001f;
+        dir = dir + mk(xj, yj, 0.0f);
+    }
+    return dir;
+}
+
+// Appends one item per lane with `want` set to a global list; returns the lane's slot.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
+    const uint64_t m = ballot64(want);
+    if (m == 0) return 0;
+    uint32_t base = 0;
+    const uint32_t lane = __lane_id();
+    const int leader = __builtin_ctzll(m);
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    const uint64_t below = m & ((1ull << lane) - 1ull);
+    return base + (uint32_t)__builtin_popcountll(below);
+}
+
+// ---- batched queries for caller-supplied rays --------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
+                                                       uint64_t n, int cull, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (valid) {
+        o = mk(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
+        d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
+    }
+    HitState h;
+    traverse<false>(T, valid, o, d, cull != 0, 0.0f, h);
+    if (valid) {
+        out_t[i] = h.t;
+        out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
+    }
+}
+
+__global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
+                                                   uint64_t n, int cull, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
+    if (valid) {
+        p = mk(point[i * 3], point[i * 3 + 1], point[i * 3 + 2]);
+        l = mk(light[i * 3], light[i * 3 + 1], light[i * 3 + 2]);
+    }
+    // renderer.cc:289-290
+    const f3 pl = l - p;
+    const float dist = length(pl);
+    const f3 d = normalize(pl);
+    HitState h;
+    traverse<true>(T, valid, p, d, cull != 0, dist, h);
+    if (valid) out[i] = h.found ? 1 : 0;
+}
+
+// ---- renderer level kernels ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __restrict__ rays, uint32_t level, uint32_t i, uint32_t n,
+                                         bool& valid, f3& o, f3& d, uint32_t& pixel, uint32_t& node_id) {
+    valid = i < n;
+    o = mk(0, 0, 0);
+    d = mk(0, 0, 1);
+    pixel = 0;
+    node_id = 1;
+    if (level == 0) {
+        int x = 0, y = 0;
+        valid = valid && node0_pixel(F, i, x, y);
+        if (valid) {
+            pixel = (uint32_t)y * (uint32_t)F.width + (uint32_t)x;
+            o = F.cam_pos;
+            d = primary_dir(F, x, y, pixel);
+        }
+    } else if (valid) {
+        const RayRec r = rays[i];
+        o = mk(r.o[0], r.o[1], r.o[2]);
+        d = mk(r.d[0], r.d[1], r.d[2]);
+        pixel = r.pixel;
+        node_id = r.node_id;
+    }
+}
+
+// Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
+__global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                                 float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
+                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
+    HitState h;
+    traverse<false>(S.tree, valid, o, d, F.cull != 0, 0.0f, h);
+    const bool hit = valid && !(h.t == RT_INF);
+    if (valid) {
+        hit_t[i] = h.t;
+        hit_tri[i] = hit ? (int32_t)h.tri : -1;
+        if (!hit) {  // renderer.cc:140-142: the background colour is this node's value
+            NodeOut r;
+            r.c[0] = F.bg.x; r.c[1] = F.bg.y; r.c[2] = F.bg.z;
+            for (int k = 0; k < 3; ++k) r.fR[k] = r.fT[k] = r.IR[k] = r.IT[k] = 0.0f;
+            r.flags = 0;
+            out[i] = r;
+        }
+    }
+    const uint32_t slot = wave_append(&counters[CNT_WORK], hit);
+    if (hit) work[slot] = i;
+}
+
+// src/triangle.h:54-77
+__device__ __forceinline__ f3 interpolate_normal(const LeafTri& g, const float* __restrict__ vn, f3 P) {
+    const f3 v0 = mk(g.e1x, g.e1y, g.e1z), v1 = mk(g.e2x, g.e2y, g.e2z);
+    const f3 v2 = P - mk(g.ax, g.ay, g.az);
+    const float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    const float v = (d11 * d20 - d01 * d21) / denom;
+    const float w = (d00 * d21 - d01 * d20) / denom;
+    const float u = 1.0f - v - w;
+    const f3 n0 = mk(vn[0], vn[1], vn[2]), n1 = mk(vn[3], vn[4], vn[5]), n2 = mk(vn[6], vn[7], vn[8]);
+    return normalize(((n0 * u) + (n1 * v)) + (n2 * w));
+}
+
+// Local illumination + recursion gate + secondary ray construction for every hit of one level
+// (renderer.cc:144-192, 202-335).
+__global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                               const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
+                                               const uint32_t* __restrict__ work, NodeOut* __restrict__ out, RayRec* __restrict__ next,
+                                               uint32_t next_cap, uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_work = counters[CNT_WORK];
+    const bool active = j < n_work;
+    uint32_t i = 0;
+    if (active) i = work[j];
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
+    valid = valid && active;
+    float t = 0.0f;
+    uint32_t tri = 0;
+    if (valid) {
+        t = hit_t[i];
+        tri = (uint32_t)hit_tri[i];
+    }
+    const TriShade ts = S.tri_shade[tri];
+    const MatDev m = S.mats[valid ? ts.mat : 0];
+    const f3 P = o + (d * t);  // renderer.cc:146
+    f3 N = mk(ts.nx, ts.ny, ts.nz);
+    if (F.shading_type == 1 && valid) N = interpolate_normal(S.tri_geom[tri], S.tri_vnorm + (size_t)tri * 9, P);
+    const f3 diffuse = mk(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+    const f3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
+
+    f3 col = mk(0, 0, 0);
+    uint32_t shadow_rays = 0;  // wave-uniform
+    if (F.render_type == 0) {  // renderer.cc:197-200
+        const float g = 1.0f - (std_min(t, 1.5f * F.max_distance) / (1.5f * F.max_distance));
+        col = col + mk(g, g, g);
+    } else if (F.render_type == 1) {
+        col = col + diffuse;
+    } else {  // renderer.cc:202-247
+        const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
+        bool live = valid;          // still inside render_local_ilumination's light loop
+        f3 final_c = mk(0, 0, 0);
+        for (uint32_t l = 0; l < S.n_lights; ++l) {
+            const LightDev L = S.lights[l];
+            if (live && ts.light_eq == (int32_t)l) {  // renderer.cc:212-214: the hit triangle is this light
+                final_c = mk(L.emission[0], L.emission[1], L.emission[2]);
+                live = false;
+            }
+            if (ballot64(live) == 0) break;
+            const f3 la = mk(L.a[0], L.a[1], L.a[2]), le1 = mk(L.e1[0], L.e1[1], L.e1[2]), le2 = mk(L.e2[0], L.e2[1], L.e2[2]);
+            const f3 n_l = mk(L.n[0], L.n[1], L.n[2]);
+            const f3 emission = mk(L.emission[0], L.emission[1], L.emission[2]);
+            f3 acc = mk(0, 0, 0);
+            for (int s = 0; s < F.spt; ++s) {
+                // src/triangle.h:42-52
+                const float r1 = u31_to_float(rng_finish(pre, l, (uint32_t)s, 0));
+                const float r2 = u31_to_float(rng_finish(pre, l, (uint32_t)s, 1));
+                const float uu = (r1 + r2 > 1.0f) ? 1.0f - r1 : r1;
+                const float vv = (r1 + r2 > 1.0f) ? 1.0f - r2 : r2;
+                const f3 p_l = (la + (le1 * uu)) + (le2 * vv);
+                // renderer.cc:288-313
+                const f3 to_l = p_l - P;
+                const float dist = length(to_l);
+                const f3 d_l = normalize(to_l);
+                HitState h;
+                shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
+                traverse<true>(S.tree, live, P, d_l, F.cull != 0, dist, h);
+                if (live && !h.found) {  // renderer.cc:220-240
+                    const float w = (L.area * std_max(0.0f, dot(n_l, -d_l))) / ((float)F.spt * dist * dist + kEps);
+                    const f3 I_l = emission * w;
+                    const f3 d_v = normalize(F.cam_pos - P);
+                    const f3 I_a = I_l * mk(0, 0, 0);
+                    const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));
+                    f3 c;
+                    if (F.render_type == 2) {  // renderer.cc:249-267
+                        const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
+                        const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
+                        c = ((I_a + I_d) + I_s) + mk(m.emission[0], m.emission[1], m.emission[2]);
+                    } else {  // renderer.cc:269-286
+                        const f3 d_h = normalize(d_l + d_v);
+                        const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(N, d_h)), m.shininess);
+                        c = (I_a + I_d) + I_s;
+                    }
+                    acc = acc + c;
+                }
+            }
+            if (live) final_c = final_c + acc;
+        }
+        col = col + final_c;
+    }
+    col = clamp_color(col);  // renderer.cc:170
+
+    // renderer.cc:172-192
+    bool want_R = false, want_T = false;
+    f3 dir_R = mk(0, 0, 0), dir_T = mk(0, 0, 0);
+    if (valid && !eq_eps(col, mk(1.0f, 1.0f, 1.0f)) && (int)level < F.max_depth) {
+        const f3 d_v = -d;
+        if (m.has_specular) {  // renderer.cc:315-321
+            const f3 d_r = ((N * 2.0f) * dot(N, d_v)) - d_v;
+            dir_R = normalize(d_r);
+            want_R = true;
+        }
+        if (m.has_transmittance) {  // renderer.cc:323-335; the sqrt and the subtraction run in double there
+            const float nn = 1.0f / m.ior;
+            const float ndotv = dot(N, d_v);
+            const double root = sqrt((double)(1.0f - nn * nn * (1.0f - ndotv * ndotv)));
+            const float coef = (float)((double)(nn * ndotv) - root);
+            const f3 tt = (d_v * -nn) + (N * coef);
+            if (length(tt) > kEps) dir_T = normalize(tt);
+            want_T = !eq_eps(dir_T, mk(0, 0, 0));  // renderer.cc:187
+        }
+    }
+    if (valid) {
+        NodeOut r;
+        r.c[0] = col.x; r.c[1] = col.y; r.c[2] = col.z;
+        for (int k = 0; k < 3; ++k) {
+            r.fR[k] = m.specular[k];
+            r.fT[k] = m.transmittance[k];
+            r.IR[k] = r.IT[k] = 0.0f;
+        }
+        r.flags = (want_R ? 1u : 0u) | (want_T ? 2u : 0u);
+        out[i] = r;
+    }
+    const uint32_t sR = wave_append(&counters[CNT_NEXT], want_R);
+    const uint32_t sT = wave_append(&counters[CNT_NEXT], want_T);
+    if (want_R && sR < next_cap) {
+        RayRec r;
+        r.o[0] = P.x; r.o[1] = P.y; r.o[2] = P.z;
+        r.d[0] = dir_R.x; r.d[1] = dir_R.y; r.d[2] = dir_R.z;
+        r.parent = i; r.pixel = pixel; r.node_id = node_id * 2;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        next[sR] = r;
+    }
+    if (want_T && sT < next_cap) {
+        RayRec r;
+        r.o[0] = P.x; r.o[1] = P.y; r.o[2] = P.z;
+        r.d[0] = dir_T.x; r.d[1] = dir_T.y; r.d[2] = dir_T.z;
+        r.parent = i; r.pixel = pixel; r.node_id = node_id * 2 + 1;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        next[sT] = r;
+    }
+    if (__lane_id() == 0 && shadow_rays) {
+        const uint32_t old = atomicAdd(&counters[CNT_SHADOW_LO], shadow_rays);
+        if (old + shadow_rays < old) atomicAdd(&counters[CNT_SHADOW_HI], 1u);
+    }
+}
+
+// renderer.cc:181-182,188-189: final += I_R * specular; final += I_T * transmittance -- evaluated bottom-up,
+// one level per launch, each node handing its value to its parent.
+__device__ __forceinline__ f3 node_value(const NodeOut& r) {
+    f3 v = mk(r.c[0], r.c[1], r.c[2]);
+    if (r.flags & 1u) v = v + (mk(r.IR[0], r.IR[1], r.IR[2]) * mk(r.fR[0], r.fR[1], r.fR[2]));
+    if (r.flags & 2u) v = v + (mk(r.IT[0], r.IT[1], r.IT[2]) * mk(r.fT[0], r.fT[1], r.fT[2]));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_resolve(const NodeOut* __restrict__ cur, const RayRec* __restrict__ rays, uint32_t n,
+                                                 NodeOut* __restrict__ parent_level) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 v = node_value(cur[i]);
+    const RayRec r = rays[i];
+    float* dst = (r.node_id & 1u) ? parent_level[r.parent].IT : parent_level[r.parent].IR;
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+}
+
+// renderer.cc:42-51: sum over the samples of a pixel, divide, clamp.
+__global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const NodeOut* __restrict__ level0, uint32_t n,
+                                                        float* __restrict__ accum, float* __restrict__ out_rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y;
+    if (!node0_pixel(F, i, x, y)) return;
+    const size_t pix = (size_t)y * F.width + x;
+    f3 v = node_value(level0[i]);
+    if (F.spp_sample > 0) v = mk(accum[i * 3], accum[i * 3 + 1], accum[i * 3 + 2]) + v;
+    if ((int)F.spp_sample + 1 < F.spp) {
+        accum[i * 3] = v.x; accum[i * 3 + 1] = v.y; accum[i * 3 + 2] = v.z;
+    } else {
+        v = clamp_color(div_guard(v, (float)F.spp));
+        out_rgb[pix * 3] = v.x; out_rgb[pix * 3 + 1] = v.y; out_rgb[pix * 3 + 2] = v.z;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_primary_hits(FrameParams F, const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
+                                                      uint32_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y;
+    if (!node0_pixel(F, i, x, y)) return;
+    const size_t pix = (size_t)y * F.width + x;
+    out_t[pix] = hit_t[i];
+    out_tri[pix] = hit_tri[i];
+}
+
+// ---- Ads::Search restated (octree.cc:173-207): breadth-first, one ray per thread, queue in a workspace ---------------
+
+template <bool FILL>
+__global__ void __launch_bounds__(64) k_search(DevOctree T, const float* __restrict__ rays, uint32_t n, uint32_t* __restrict__ queue,
+                                               uint32_t queue_cap, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+                                               uint32_t* __restrict__ out_tri) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 o = mk(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+    const f3 d = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t* q = queue + (size_t)i * queue_cap * 2;
+    uint64_t total = 0;
+    uint64_t w = FILL ? offsets[i] : 0;
+    uint32_t qh = 0, qt = 0;
+    if (T.root_info1 != 0) {
+        q[0] = T.root_info0;
+        q[1] = T.root_info1;
+        qt = 1;
+    }
+    while (qh < qt) {
+        const uint32_t i0 = q[qh * 2], i1 = q[qh * 2 + 1];
+        ++qh;
+        if (!(i1 & kChildInternal)) {
+            if (FILL)
+                for (uint32_t k = 0; k < i1; ++k) out_tri[w + k] = T.slots[i0 + k].tri;
+            w += i1;
+            total += i1;
+            continue;
+        }
+        const NodeRec& r = T.nodes[i0];
+        for (int c = 0; c < 8; ++c) {
+            if (r.info[c][1] == 0) continue;
+            if (!ray_box(o, inv, r.box[c][0], r.box[c][1], r.box[c][2], r.box[c][3], r.box[c][4], r.box[c][5])) continue;
+            if (qt < queue_cap) {
+                q[qt * 2] = r.info[c][0];
+                q[qt * 2 + 1] = r.info[c][1];
+            }
+            ++qt;
+        }
+    }
+    if (!FILL) counts[i] = (qt > queue_cap) ? ~0ull : total;
+}
+
+}  // namespace rt

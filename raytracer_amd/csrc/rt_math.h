@@ -1,0 +1,81 @@
+// rt_math.h -- float3 arithmetic shared by the host octree builder and the gfx950 kernels.
+//
+// Every operation is written in the association order of the reference's Vec3
+// (src/vec3.h:23-64 of the reference) and the whole library is compiled with
+// -ffp-contract=off, so that host and device round exactly like the reference's
+// x86-64 build (which has no FMA): bit-identical boxes, hit distances and tie-breaks
+// depend on it.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+constexpr float kEps = 1e-9f;  // src/util.h:9
+#define RT_INF (__builtin_inff())
+
+struct f3 {
+    float x, y, z;
+};
+
+RT_HD f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+RT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+RT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+RT_HD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+// src/vec3.h:25 -- guarded division: |s| <= eps gives the zero vector.
+RT_HD f3 div_guard(f3 a, float s) { return fabsf(s) > kEps ? f3{a.x / s, a.y / s, a.z / s} : f3{0.f, 0.f, 0.f}; }
+// src/vec3.h:32 -- epsilon equality.
+RT_HD bool eq_eps(f3 a, f3 b) { return fabsf(a.x - b.x) < kEps && fabsf(a.y - b.y) < kEps && fabsf(a.z - b.z) < kEps; }
+RT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD f3 cross(f3 a, f3 b) { return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_HD f3 vabs(f3 a) { return f3{fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
+// src/vec3.h:43 -- the reference calls ::sqrt(double) on the float sum and narrows the result, which
+// equals the correctly rounded float square root.
+RT_HD float length(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RT_HD f3 normalize(f3 a) { return div_guard(a, length(a)); }
+RT_HD float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// std::max(a,b) = (a<b)?b:a and std::min(a,b) = (b<a)?b:a: a NaN second argument is ignored, a NaN
+// first argument is kept.  The slab test relies on this (src/collision_detection.h:82-83).
+RT_HD float std_max(float a, float b) { return (a < b) ? b : a; }
+RT_HD float std_min(float a, float b) { return (b < a) ? b : a; }
+RT_HD float clamp01(float v) { return std_max(std_min(v, 1.0f), 0.0f); }  // src/util.h:13-16, src/color.h:17-19
+RT_HD f3 clamp_color(f3 c) { return f3{clamp01(c.x), clamp01(c.y), clamp01(c.z)}; }
+
+// The shared counter-based generator: a chain of 32-bit avalanche steps over the key fields, reduced to
+// 31 bits so that it maps to float exactly like (float)rand() / (float)RAND_MAX (src/triangle.h:43-44,
+// src/Renderer/renderer.cc:44-45): k / 2^31, which can round to 1.0.
+RT_HD uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7feb352dU;
+    h ^= h >> 15;
+    h *= 0x846ca68bU;
+    h ^= h >> 16;
+    return h;
+}
+RT_HD uint32_t rng_prefix(uint32_t seed, uint32_t pixel, uint32_t spp_sample, uint32_t node_id) {
+    uint32_t h = mix32(seed + 0x9e3779b9U);
+    h = mix32(h ^ pixel);
+    h = mix32(h ^ (spp_sample + 0x85ebca6bU));
+    h = mix32(h ^ (node_id + 0xc2b2ae35U));
+    return h;
+}
+RT_HD uint32_t rng_finish(uint32_t prefix, uint32_t light, uint32_t sample, uint32_t dim) {
+    uint32_t h = mix32(prefix ^ (light + 0x27d4eb2fU));
+    h = mix32(h ^ (sample + 0x165667b1U));
+    h = mix32(h ^ (dim + 0xd3a2646cU));
+    return h >> 1;
+}
+RT_HD float u31_to_float(uint32_t k) { return (float)(int32_t)k / 2147483648.0f; }  // (float)RAND_MAX == 2^31
+
+}  // namespace rt

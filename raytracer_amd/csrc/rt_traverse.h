@@ -1,0 +1,217 @@
+// rt_traverse.h -- wave64 octree traversal + ray/triangle test for gfx950 (device only).
+//
+// One ray per lane, 64 rays per wavefront, traversed TOGETHER: the wave walks the union of the
+// nodes its rays reach, and each stack entry carries the 64-bit ballot of the lanes that reached
+// it.  Because the node being worked on is the same for every lane, node records and triangle
+// records are fetched with scalar loads (s_load through the constant cache) and feed the VALU as
+// SGPR operands; no vector memory instruction and no LDS is needed inside the loop.  The stack
+// itself lives in registers: entry i of the wave-uniform stack is stored in lane i of a VGPR
+// (written with a lane-select, read with v_readlane), two VGPRs per field for up to 128 entries.
+//
+// The set of (ray, triangle) tests performed is exactly the candidate set of the reference's
+// Octree::Search (src/ADS/Octree/octree.cc:173-207 of the reference): a triangle reference is
+// tested iff the ray passes the slab test of every box on the path from the root's children down
+// to its leaf; the root box is never tested; empty octants are skipped.  The traversal order is
+// depth-first instead of the reference's breadth-first; the closest-hit reduction therefore keys
+// ties on the global leaf-slot index, which is the reference's candidate-list order (see
+// host_octree.h).  For any-hit queries a lane retires as soon as it has found an occluder (the
+// result is a boolean, src/Renderer/renderer.cc:302-306).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "host_octree.h"
+#include "rt_math.h"
+
+namespace rt {
+
+#define RT_CONST __attribute__((address_space(4)))
+
+struct DevOctree {
+    const NodeRec* nodes;
+    const LeafTri* slots;
+    uint32_t root_info0, root_info1;
+    uint32_t n_nodes, n_slots;
+};
+
+typedef const RT_CONST float* cfloat_p;
+typedef const RT_CONST uint32_t* cu32_p;
+
+__device__ __forceinline__ cfloat_p as_const_f(const void* p) { return (cfloat_p)(uintptr_t)p; }
+__device__ __forceinline__ cu32_p as_const_u(const void* p) { return (cu32_p)(uintptr_t)p; }
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Writes the wave-uniform value v into lane `idx` of the per-lane register `old` (a v_writelane; this
+// compiler exposes no builtin for it, and a compare + select is what it lowers to anyway).
+__device__ __forceinline__ int write_lane(int v, int idx, int old) { return ((int)__lane_id() == idx) ? v : old; }
+
+// Moeller-Trumbore exactly as src/collision_detection.h:12-68: same operation order, the same
+// comparisons (so NaNs fall through the same way), 1/d as a correctly rounded division.
+// Returns +inf on a miss.
+__device__ __forceinline__ float ray_triangle(f3 o, f3 s, f3 a, f3 e1, f3 e2, bool cull) {
+    const f3 p = cross(s, e2);
+    const float d = dot(e1, p);
+    const bool reject = cull ? (d < kEps) : (fabsf(d) < kEps);
+    float t = RT_INF;
+    if (!reject) {
+        const float d_inv = 1.0f / d;
+        const f3 q = o - a;
+        const float u = d_inv * dot(q, p);
+        if (!(u < 0.0f || u > 1.0f)) {
+            const f3 w = cross(q, e1);
+            const float v = d_inv * dot(w, s);
+            if (!(v < 0.0f || (u + v) > 1.0f)) t = d_inv * dot(e2, w);
+        }
+    }
+    return t;
+}
+
+// Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the
+// reference recomputes the same three quotients for every box).
+__device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
+    float t_min = -RT_INF, t_max = RT_INF;
+    {
+        float t0 = (bx0 - o.x) * inv.x, t1 = (bx1 - o.x) * inv.x;
+        if (inv.x < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = std_max(t_min, t0);
+        t_max = std_min(t_max, t1);
+    }
+    {
+        float t0 = (by0 - o.y) * inv.y, t1 = (by1 - o.y) * inv.y;
+        if (inv.y < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = std_max(t_min, t0);
+        t_max = std_min(t_max, t1);
+    }
+    {
+        float t0 = (bz0 - o.z) * inv.z, t1 = (bz1 - o.z) * inv.z;
+        if (inv.z < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = std_max(t_min, t0);
+        t_max = std_min(t_max, t1);
+    }
+    return t_max >= t_min;
+}
+
+struct HitState {
+    float t;        // closest: best t so far (+inf = none)
+    uint32_t slot;  // closest: global leaf slot of the winner
+    uint32_t tri;   // closest: its triangle index
+    bool found;     // any-hit: occluder found
+};
+
+// Tests the triangles of leaf slots [begin, begin+count) for the lanes with `mine` set.
+template <bool ANY>
+__device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, bool mine, f3 o, f3 d, bool cull,
+                                           float t_limit, HitState& h) {
+    cfloat_p base = as_const_f(T.slots);
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t slot = begin + k;
+        cfloat_p r = base + (size_t)slot * 12;
+        const f3 a = mk(r[0], r[1], r[2]);
+        const f3 e1 = mk(r[3], r[4], r[5]);
+        const f3 e2 = mk(r[6], r[7], r[8]);
+        const uint32_t tri = __float_as_uint(r[9]);
+        if (mine) {
+            const float t = ray_triangle(o, d, a, e1, e2, cull);
+            if (!(t == RT_INF || t < kEps)) {  // renderer.cc:126 / :298
+                if (ANY) {
+                    if (t < t_limit) h.found = true;  // renderer.cc:302
+                } else {
+                    // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
+                    // smaller global slot.
+                    if (t < h.t || (t == h.t && slot < h.slot)) {
+                        h.t = t;
+                        h.slot = slot;
+                        h.tri = tri;
+                    }
+                }
+            }
+        }
+        if (ANY) {
+            mine = mine && !h.found;
+            if (ballot64(mine) == 0) break;
+        }
+    }
+}
+
+// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
+template <bool ANY>
+__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, bool cull, float t_limit, HitState& h) {
+    h.t = RT_INF;
+    h.slot = 0xffffffffu;
+    h.tri = 0xffffffffu;
+    h.found = false;
+    if (T.root_info1 == 0) return;  // empty tree
+    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
+        leaf_tests<ANY>(T, T.root_info0, T.root_info1, valid, o, d, cull, t_limit, h);
+        return;
+    }
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
+    const uint32_t lane = __lane_id();
+    const uint32_t lane_bit = 1u << (lane & 31);
+    const bool upper = lane >= 32;
+
+    // Register-resident wave-uniform stack: entry i lives in lane (i & 63) of stack register (i >> 6).
+    int s_node0 = 0, s_node1 = 0, s_mlo0 = 0, s_mlo1 = 0, s_mhi0 = 0, s_mhi1 = 0;
+    int sp = 0;
+    {
+        const uint64_t m = ballot64(valid);
+        if (m == 0) return;
+        s_node0 = write_lane((int)T.root_info0, 0, s_node0);
+        s_mlo0 = write_lane((int)(uint32_t)m, 0, s_mlo0);
+        s_mhi0 = write_lane((int)(uint32_t)(m >> 32), 0, s_mhi0);
+        sp = 1;
+    }
+    cu32_p nodes = as_const_u(T.nodes);
+    while (sp > 0) {
+        --sp;
+        uint32_t ni, mlo, mhi;
+        if (sp < 64) {
+            ni = (uint32_t)__builtin_amdgcn_readlane(s_node0, sp);
+            mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo0, sp);
+            mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi0, sp);
+        } else {
+            ni = (uint32_t)__builtin_amdgcn_readlane(s_node1, sp - 64);
+            mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo1, sp - 64);
+            mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi1, sp - 64);
+        }
+        bool mine = ((upper ? mhi : mlo) & lane_bit) != 0;
+        if (ANY) {
+            mine = mine && !h.found;
+            if (ballot64(mine) == 0) continue;
+        }
+        cu32_p rec = nodes + (size_t)ni * 64;
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t info1 = rec[48 + c * 2 + 1];
+            if (info1 == 0) continue;  // null or empty octant (octree.cc:195)
+            const uint32_t info0 = rec[48 + c * 2];
+            const float bx0 = __uint_as_float(rec[c * 6 + 0]), by0 = __uint_as_float(rec[c * 6 + 1]), bz0 = __uint_as_float(rec[c * 6 + 2]);
+            const float bx1 = __uint_as_float(rec[c * 6 + 3]), by1 = __uint_as_float(rec[c * 6 + 4]), bz1 = __uint_as_float(rec[c * 6 + 5]);
+            const bool pass = mine && ray_box(o, inv, bx0, by0, bz0, bx1, by1, bz1);
+            const uint64_t pm = ballot64(pass);
+            if (pm == 0) continue;
+            if (info1 & kChildInternal) {
+                if (sp < 64) {
+                    s_node0 = write_lane((int)info0, sp, s_node0);
+                    s_mlo0 = write_lane((int)(uint32_t)pm, sp, s_mlo0);
+                    s_mhi0 = write_lane((int)(uint32_t)(pm >> 32), sp, s_mhi0);
+                } else {
+                    s_node1 = write_lane((int)info0, sp - 64, s_node1);
+                    s_mlo1 = write_lane((int)(uint32_t)pm, sp - 64, s_mlo1);
+                    s_mhi1 = write_lane((int)(uint32_t)(pm >> 32), sp - 64, s_mhi1);
+                }
+                ++sp;
+            } else {
+                leaf_tests<ANY>(T, info0, info1, pass, o, d, cull, t_limit, h);
+                if (ANY) {
+                    mine = mine && !h.found;
+                    if (ballot64(mine) == 0) break;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rt

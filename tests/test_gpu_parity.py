@@ -1,0 +1,193 @@
+"""GPU parity tests: every query entry point of the C ABI against the oracle on the same inputs.
+
+Bar: hit distances, triangle indices, occlusion flags and candidate lists bit-exact; images of the
+RNG-free render types bit-exact; Phong / Blinn-Phong images within 1/255 per channel (device powf is
+not libm's); ray counts equal to the oracle's Search-call counts."""
+import numpy as np
+import pytest
+
+from conftest import CAMERAS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    return raytracer_amd
+
+
+def build(rt, sc, mb=16, md=10):
+    g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+    g.Build(sc.pos)
+    g.set_shading(sc.norm if sc.has_normals else None, sc.matid, sc.materials)
+    return g
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def primary_rays(orc, scene, w, h):
+    cfg = orc.make_cfg(fov=0.6, width=w, height=h, **CAMERAS[scene])
+    d = orc.generate_rays(cfg).reshape(-1, 3)
+    o = np.tile(np.asarray(CAMERAS[scene]["cam_pos"], np.float32), (d.shape[0], 1))
+    return o, d
+
+
+def random_rays(sc, n, seed):
+    rs = np.random.RandomState(seed)
+    lo, hi = sc.pos.reshape(-1, 3).min(0), sc.pos.reshape(-1, 3).max(0)
+    o = (lo + (hi - lo) * rs.rand(n, 3) * 1.4 - 0.2 * (hi - lo)).astype(np.float32)
+    d = rs.randn(n, 3).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # axis-parallel directions and exact zeros exercise the inf / NaN paths of the slab test
+    d[::7, 0] = 0.0
+    d[::11, 1] = 0.0
+    d[::13, 2] = -0.0
+    d[5::97] = [0.0, 0.0, 1.0]
+    o[3::50] = sc.pos.reshape(-1, 3)[rs.randint(0, sc.pos.size // 3, len(o[3::50]))]  # origins on vertices
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3), ("original", 1000, 10)])
+@pytest.mark.parametrize("cull", [True, False])
+def test_trace_closest(rt, orc, scenes, scene, mb, md, cull):
+    sc = scenes[scene]
+    g = build(rt, sc, mb, md)
+    ot = orc.Octree(sc, mb, md)
+    o1, d1 = primary_rays(orc, scene, 96, 64)
+    o2, d2 = random_rays(sc, 20000, 7)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    t_ref, tri_ref = ot.trace_closest(o, d, cull)
+    t, tri = g.trace_closest(o, d, cull)
+    assert np.array_equal(tri, tri_ref)
+    assert np.array_equal(bits(t), bits(t_ref))
+    assert (tri >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize("scene", ["original", "sphere"])
+def test_trace_any(rt, orc, scenes, scene):
+    sc = scenes[scene]
+    g = build(rt, sc)
+    ot = orc.Octree(sc, 16, 10)
+    o, d = primary_rays(orc, scene, 128, 96)
+    t, tri = ot.trace_closest(o, d, True)
+    hit = tri >= 0
+    P = (o + d * t[:, None])[hit].astype(np.float32)
+    rs = np.random.RandomState(3)
+    lt = sc.pos[sc.light_tri[rs.randint(0, sc.n_light, P.shape[0])]]
+    u, v = rs.rand(P.shape[0], 1).astype(np.float32), rs.rand(P.shape[0], 1).astype(np.float32)
+    L = (lt[:, 0] + (lt[:, 1] - lt[:, 0]) * u * 0.5 + (lt[:, 2] - lt[:, 0]) * v * 0.5).astype(np.float32)
+    for cull in (True, False):
+        ref = ot.trace_any(P, L, cull)
+        got = g.trace_any(P, L, cull)
+        assert np.array_equal(ref, got)
+        assert 0 < ref.sum() < ref.size
+
+
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3)])
+def test_search_candidate_lists(rt, orc, scenes, scene, mb, md):
+    sc = scenes[scene]
+    g = build(rt, sc, mb, md)
+    ot = orc.Octree(sc, mb, md)
+    o, d = random_rays(sc, 300, 11)
+    got = g.search_batch(np.concatenate([o, d], axis=1))
+    for i in range(o.shape[0]):
+        assert np.array_equal(got[i], ot.search(o[i], d[i])), i
+    one = g.Search(np.concatenate([o[0], d[0]]))
+    assert np.array_equal(one, ot.search(o[0], d[0]))
+
+
+def test_empty_and_tiny_scenes(rt, orc, scenes):
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    g.Build(np.zeros((0, 3, 3), np.float32))
+    t, tri = g.trace_closest([[0, 0, 0]], [[0, 0, 1]])
+    assert tri[0] == -1 and np.isinf(t[0])
+    assert len(g.Search([0, 0, 0, 0, 0, 1])) == 0
+    sc = orc.Scene.from_arrays(scenes["original"].pos[:5], None, scenes["original"].matid[:5], scenes["original"].materials)
+    g = build(rt, sc)
+    assert g.tree_stats()["nodes"] == 1
+    ot = orc.Octree(sc, 16, 10)
+    o, d = random_rays(sc, 2000, 5)
+    t_ref, tri_ref = ot.trace_closest(o, d, False)
+    t, tri = g.trace_closest(o, d, False)
+    assert np.array_equal(tri, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+    assert np.array_equal(g.Search(np.concatenate([o[0], d[0]])), np.arange(5))
+
+
+def test_tree_stats_match_reference(rt, scenes):
+    g = build(rt, scenes["sphere"])
+    st = g.tree_stats()
+    assert (st["nodes"], st["leaves"], st["max_triangles_in_leaf"], st["max_depth"]) == (1584, 1300, 34, 10)
+
+
+RENDER_CASES = [
+    # name, scene, render_type, shading, w, h, spt, spp, cull, exact
+    ("orig_distance", "original", "distance", "flat", 128, 128, 1, 1, True, True),
+    ("orig_distance_wide", "original", "distance", "flat", 200, 120, 1, 1, True, True),
+    ("sphere_diffusion", "sphere", "diffusion", "smooth", 128, 128, 1, 1, True, True),
+    ("sphere_distance_nocull", "sphere", "distance", "flat", 128, 128, 1, 1, False, True),
+    ("orig_blinn", "original", "blinn_phong", "flat", 96, 96, 4, 1, True, False),
+    ("orig_phong_tall", "original", "phong", "flat", 64, 96, 2, 1, True, False),
+    ("sphere_phong", "sphere", "phong", "smooth", 64, 64, 2, 1, True, False),
+    ("sphere_blinn_spp", "sphere", "blinn_phong", "smooth", 64, 64, 2, 3, True, False),
+    ("sphere_diffusion_spp", "sphere", "diffusion", "smooth", 61, 45, 1, 2, True, True),
+]
+
+
+@pytest.mark.parametrize("case", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
+def test_render_matches_oracle(rt, orc, scenes, case):
+    name, scene, rtype, shading, w, h, spt, spp, cull, exact = case
+    sc = scenes[scene]
+    g = build(rt, sc)
+    ot = orc.Octree(sc, 16, 10)
+    cam = CAMERAS[scene]
+    ocfg = orc.make_cfg(fov=0.6, width=w, height=h, spp=spp, spt=spt, render_type=rtype, shading=shading, cull=cull,
+                        rng_mode=orc.RNG_COUNTER, **cam)
+    ref, ref_tri, ref_t, st = orc.render(sc, ot, ocfg)
+    gcfg = rt.make_render_config(fov=0.6, width=w, height=h, spp=spp, spt=spt, render_type=rtype, shading=shading, cull=cull, **cam)
+    img, gst = g.render(gcfg)
+    t, tri = g.primary_hits(gcfg)
+    assert np.array_equal(tri, ref_tri)
+    assert np.array_equal(bits(t), bits(ref_t))
+    # one ray = one Search call of the reference
+    assert gst.rays == st.search_calls
+    assert gst.primary_rays == st.primary_rays and gst.secondary_rays == st.secondary_rays and gst.shadow_rays == st.shadow_rays
+    if exact:
+        assert np.array_equal(bits(img), bits(ref))
+        assert orc.ppm_md5(img) == orc.ppm_md5(ref)
+    else:
+        assert np.abs(img - ref).max() <= 1.0 / 255.0
+        q = lambda a: (255.999 * a.astype(np.float64)).astype(np.int64)
+        assert np.abs(q(img) - q(ref)).max() <= 1
+
+
+def test_render_is_partition_independent(rt, scenes):
+    """Rendering the image in interleaved bands (as 2 or 3 ranks would) gives the same pixels as one call."""
+    sc = scenes["original"]
+    g = build(rt, sc)
+    cam = CAMERAS["original"]
+    kw = dict(fov=0.6, width=72, height=100, spt=3, render_type="blinn_phong", shading="flat", **cam)
+    full, _ = g.render(rt.make_render_config(**kw))
+    for world in (2, 3):
+        out = np.zeros_like(full)
+        rays = 0
+        for r in range(world):
+            _, st = g.render(rt.make_render_config(band_rank=r, band_world=world, **kw), out=out)
+            rays += st.rays
+        assert np.array_equal(bits(out), bits(full))
+
+
+def test_errors(rt, scenes):
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    with pytest.raises(RuntimeError, match="rt_ads_build"):
+        g.trace_closest([[0, 0, 0]], [[0, 0, 1]])
+    with pytest.raises(KeyError):
+        rt.GpuOctree({"max_depth": 10})
+    sc = scenes["original"]
+    g = build(rt, sc)
+    with pytest.raises(RuntimeError, match="smooth shading needs vertex normals"):
+        g.render(rt.make_render_config(fov=0.6, width=8, height=8, shading="smooth", **CAMERAS["original"]))
+    with pytest.raises(RuntimeError, match="samples_per_pixel"):
+        g.render(rt.make_render_config(fov=0.6, width=8, height=8, spp=0, **CAMERAS["original"]))

@@ -1,0 +1,103 @@
+"""CPU tests of the product's host logic: the octree built by the library (without a GPU) must equal the
+oracle's tree bit for bit, the flattened device layout must be a faithful re-encoding of it, and the
+shared library must export every symbol include/raytracer_amd.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from raytracer_amd import _capi
+from raytracer_amd.ads import HostTree, ads_kind_from_name
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+@pytest.mark.parametrize("scene", ["original", "sphere"])
+@pytest.mark.parametrize("mb,md", [(16, 10), (4, 3), (1000000, 10), (1, 2), (8, 0)])
+def test_tree_equals_oracle(orc, scenes, scene, mb, md):
+    sc = scenes[scene]
+    oe = orc.Octree(sc, mb, md).export()
+    ht = HostTree(sc.pos, mb, md)
+    he = ht.export()
+    for k in oe:
+        assert same_bits(oe[k], he[k]), k
+    os_, hs = orc.Octree(sc, mb, md).stats(), ht.stats()
+    assert (os_["nodes"], os_["leaves"], os_["max_depth"], os_["max_tris_in_leaf"], os_["leaf_refs"]) == \
+           (hs["nodes"], hs["leaves"], hs["max_depth"], hs["max_triangles_in_leaf"], hs["leaf_refs"])
+
+
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3)])
+def test_flat_layout(scenes, scene, mb, md):
+    sc = scenes[scene]
+    ht = HostTree(sc.pos, mb, md)
+    e = ht.export()
+    recs, slots, root = ht.export_flat()
+    internal = np.flatnonzero(e["is_leaf"] == 0)
+    leaves = np.flatnonzero(e["is_leaf"] == 1)
+    assert len(recs) == len(internal) and len(slots) == int(e["tri_count"][leaves].sum())
+    rec_of = {int(n): i for i, n in enumerate(internal)}
+    slot_of, run = {}, 0
+    for n in leaves:  # breadth-first leaf order
+        slot_of[int(n)] = run
+        run += int(e["tri_count"][n])
+    assert root[1] == 0x80000000 and root[0] == 0
+    for n in internal:
+        r = recs[rec_of[int(n)]]
+        for o in range(8):
+            c = int(e["child"][n, o])
+            if c < 0:
+                assert r["info"][o, 1] == 0
+                continue
+            assert same_bits(r["box"][o, :3], e["bmin"][c]) and same_bits(r["box"][o, 3:], e["bmax"][c])
+            if e["is_leaf"][c]:
+                assert (int(r["info"][o, 0]), int(r["info"][o, 1])) == (slot_of[c], int(e["tri_count"][c]))
+            else:
+                assert (int(r["info"][o, 0]), int(r["info"][o, 1])) == (rec_of[c], 0x80000000)
+    pos = sc.pos
+    for n in leaves:
+        b, cnt = int(e["tri_begin"][n]), int(e["tri_count"][n])
+        tris = e["pool"][b:b + cnt]
+        s = slots[slot_of[int(n)]:slot_of[int(n)] + cnt]
+        assert np.array_equal(s["tri"], tris)
+        assert same_bits(s["a"], pos[tris, 0]) and same_bits(s["e1"], pos[tris, 1] - pos[tris, 0]) and \
+            same_bits(s["e2"], pos[tris, 2] - pos[tris, 0])
+    assert ht.max_stack <= 128
+
+
+def test_empty_and_root_leaf(scenes):
+    ht = HostTree(np.zeros((0, 3, 3), np.float32))
+    assert ht.n_nodes == 0 and ht.export_flat()[2][1] == 0
+    ht = HostTree(scenes["original"].pos[:5], 16, 10)
+    recs, slots, root = ht.export_flat()
+    assert ht.n_nodes == 1 and len(recs) == 0 and len(slots) == 5 and tuple(root) == (0, 5)
+
+
+def test_header_symbols_are_exported():
+    with open(os.path.join(ROOT, "include", "raytracer_amd.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations found"
+    L = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} is declared in the header but not exported"
+    assert declared == set(_capi.EXPORTS)
+
+
+def test_ads_names():
+    # renderer.cc:368-376 plus the new backend
+    assert [ads_kind_from_name(n) for n in ("none", "octree", "octee_parametric", "octree_gpu")] == [0, 1, 2, 3]
+    with pytest.raises(RuntimeError, match="Invalid data structure"):
+        ads_kind_from_name("bvh")
+
+
+def test_rng_matches_oracle(orc):
+    L, O = _capi.lib(), orc.lib()
+    rs = np.random.RandomState(1)
+    for _ in range(200):
+        a = [int(x) for x in rs.randint(0, 2**31 - 1, 7)]
+        assert L.rt_rng_u31(*a) == O.orc_rng_u31(*a)
