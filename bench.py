@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-scene query path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One step = one frame of the workload rendered through the C ABI (rt_render): primary rays, closest
+hits, area-light shadow rays (any-hit), reflection / refraction levels, with the scene resident in
+HBM.  For N > 1 (launched with torch.distributed.run, one rank per GPU) the image is cut into bands
+of 8 pixel rows dealt round-robin to the ranks, the scene is replicated, and the bands are gathered
+to rank 0 over RCCL inside the timed region; the total work is fixed ("strong" scaling).
+
+Prints ONE JSON line on rank 0.  metric = Mrays/s, one ray = one Search-equivalent query of the
+reference (primary, secondary or shadow).  `roofline` prices the dominant kernel (k_shade: the
+any-hit shadow traversals) against the FP32 vector peak using the REFERENCE algorithm's work per ray
+(3 + 18*B + 52*T flops; B slab tests and T ray/triangle tests counted by the CPU restatement), and
+`cpu_baseline` is that restatement timed on one host core on a bounded sample of the same frame.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CAM_ORIGINAL = dict(cam_pos=[278.0, 273.0, -1000.0], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=2000.0)
+CAM_SPHERE = dict(cam_pos=[0.0, 1.0, 4.42], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, -1.0], max_distance=6.0)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cornell_original_blinn_spt16_1080p": dict(
+        scene="cornell_original", cam=CAM_ORIGINAL, width=1920, height=1080, spp=1, spt=16, render_type="blinn_phong",
+        shading="flat", cull=True, max_depth=10, cpu_rows=(0, 320)),
+    # configs[2]
+    "cornell_sphere_blinn_smooth_spp4_1080p": dict(
+        scene="cornell_sphere", cam=CAM_SPHERE, width=1920, height=1080, spp=4, spt=32, render_type="blinn_phong",
+        shading="smooth", cull=True, max_depth=10, cpu_rows=(540, 545)),
+    # a small case for quick checks
+    "cornell_original_blinn_spt4_256": dict(
+        scene="cornell_original", cam=CAM_ORIGINAL, width=256, height=256, spp=1, spt=4, render_type="blinn_phong",
+        shading="flat", cull=True, max_depth=10, cpu_rows=(96, 160)),
+}
+DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
+FP32_NO_FMA_PEAK_TOPS = 78.6      # the same lanes issuing one non-fused op per clock (bit-parity forbids FMA)
+HBM_PEAK_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import raytracer_amd as rt
+    from raytracer_amd.scene import Scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
+    ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=local_rank)
+    ads.Build(scene.pos)
+    ads.set_shading(scene.norm, scene.matid, scene.materials)
+    W, H = wl["width"], wl["height"]
+    kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=wl["render_type"], shading=wl["shading"],
+              cull=wl["cull"], max_depth=wl["max_depth"], seed=42, **wl["cam"])
+    cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
+
+    bands = (H + 7) // 8
+    bands_pad = (bands + world - 1) // world * world
+    frame = torch.zeros((bands_pad * 8, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    per_rank = bands_pad // world
+    parts = [torch.empty((per_rank, 8 * W * 3), dtype=torch.float32, device="cuda") for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        _, st = ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
+        if world > 1:
+            mine = frame.view(bands_pad, 8 * W * 3)[rank::world].contiguous()
+            dist.gather(mine, parts, dst=0)
+            if rank == 0:
+                fv = frame.view(bands_pad, 8 * W * 3)
+                for r in range(world):
+                    fv[r::world] = parts[r]
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    shade_ms = closest_ms = 0.0
+    shade_launches = closest_launches = 0
+    shadow_rays = closest_rays = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays
+        shade_ms += st.ms_shade
+        closest_ms += st.ms_closest
+        shade_launches += st.launches_shade
+        closest_launches += st.launches_closest
+        shadow_rays += st.shadow_rays
+        closest_rays += st.primary_rays + st.secondary_rays
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays = int(rr.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/s (primary+secondary+shadow Search-equivalent queries)",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic camera over the Cornell-box scene dump (tests/golden/scenes); counter-based RNG",
+            "config": {"workload": args.workload, "width": W, "height": H, "samples_per_pixel": wl["spp"],
+                       "samples_per_triangle": wl["spt"], "render_type": wl["render_type"], "shading": wl["shading"],
+                       "octree": "max_triangles_per_BB=16,max_depth=10", "aspect_mode": "compat",
+                       "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)"},
+        }
+        # ---- CPU baseline + reference-work counts on a bounded sample of the same frame (rank 0, N = 1 only) ----
+        flops_any = flops_closest = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as orc
+            osc = orc.Scene.from_arrays(scene.pos, scene.norm, scene.matid, scene.materials)
+            otree = orc.Octree(osc, 16, 10)
+            r0, r1 = wl["cpu_rows"]
+            ocfg = orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(r0, r1), **kw)
+            c0 = time.perf_counter()
+            ref, _, _, ost = orc.render(osc, otree, ocfg, want_hits=False)
+            cpu_s = time.perf_counter() - c0
+            img = frame[:H].cpu().numpy()
+            diff = float(np.abs(img[r0:r1] - ref[r0:r1]).max())
+            out["cpu_baseline"] = {"value": ost.search_calls / cpu_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+                                   "sample": f"rows {r0}..{r1 - 1} of the same frame ({ost.search_calls} rays, {cpu_s:.1f} s), "
+                                             "oracle/rt_oracle.c -O2, counter RNG"}
+            out["parity_on_sample"] = {"max_abs_diff": diff, "tolerance": 1.0 / 255.0, "ok": diff <= 1.0 / 255.0}
+            n_any = max(ost.shadow_rays, 1)
+            n_closest = max(ost.primary_rays + ost.secondary_rays, 1)
+            b_any, t_any = ost.slab_tests_any / n_any, ost.tri_tests_any / n_any
+            b_cl = (ost.slab_tests - ost.slab_tests_any) / n_closest
+            t_cl = (ost.tri_tests - ost.tri_tests_any) / n_closest
+            flops_any = 3 + 18 * b_any + 52 * t_any
+            flops_closest = 3 + 18 * b_cl + 52 * t_cl
+            out["reference_work_per_ray"] = {"any_hit": {"B": b_any, "T": t_any, "flops": flops_any},
+                                             "closest_hit": {"B": b_cl, "T": t_cl, "flops": flops_closest}}
+        if flops_any is not None and shade_ms > 0:
+            tflops = shadow_rays * flops_any / (shade_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "valu", "kernel": "k_shade (any-hit shadow traversals + shading)",
+                "achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "frac_of_no_fma_issue_peak": tflops / FP32_NO_FMA_PEAK_TOPS,
+                "traffic": None,
+                "launches": shade_launches, "avg_launch_ms": shade_ms / max(shade_launches, 1),
+                "rays_per_launch": shadow_rays / max(shade_launches, 1), "algorithmic_flops_per_ray": flops_any,
+                "kernel_Mrays_per_s": shadow_rays / (shade_ms * 1e-3) / 1e6,
+                "closest_kernel": {"avg_launch_ms": closest_ms / max(closest_launches, 1), "launches": closest_launches,
+                                   "Mrays_per_s": closest_rays / max(closest_ms * 1e-3, 1e-12) / 1e6,
+                                   "achieved_TFLOPs": closest_rays * flops_closest / max(closest_ms * 1e-3, 1e-12) / 1e12},
+            }
+        else:
+            out["roofline"] = {"bound": "valu", "kernel": "k_shade", "achieved": None, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "avg_launch_ms": shade_ms / max(shade_launches, 1), "launches": shade_launches,
+                               "kernel_Mrays_per_s": shadow_rays / max(shade_ms * 1e-3, 1e-12) / 1e6}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ class RenderCfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "search_calls", "search_nodes", "search_leaves", "search_returned", "tri_tests", "slab_tests",
-        "primary_rays", "secondary_rays", "shadow_rays")]
+        "primary_rays", "secondary_rays", "shadow_rays", "slab_tests_any", "tri_tests_any")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

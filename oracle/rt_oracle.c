@@ -785,17 +785,19 @@ void orc_trace_closest(const orc_scene* s, const orc_octree* t, uint64_t n, cons
 static int is_shadowed(const orc_scene* s, const orc_octree* t, int ads, cand_t* c, v3 p, v3 light, int cull, orc_stats* st) {
     float dist_light = v_len(v_sub(light, p));
     v3 dir = v_norm(v_sub(light, p));
+    uint64_t slab0 = st ? st->slab_tests : 0;
     if (st) st->shadow_rays++;
     search(t, ads, p, dir, c, st);
+    if (st) st->slab_tests_any += st->slab_tests - slab0;
     for (uint64_t i = 0; i < c->n; ++i) {
         float sh = ray_triangle(p, dir, &s->tri[c->idx[i]], cull);
         if (sh == INF || sh < EPS) continue;
         if (sh < dist_light) {
-            if (st) st->tri_tests += i + 1;
+            if (st) { st->tri_tests += i + 1; st->tri_tests_any += i + 1; }
             return 1;
         }
     }
-    if (st) st->tri_tests += c->n;
+    if (st) { st->tri_tests += c->n; st->tri_tests_any += c->n; }
     return 0;
 }
 

@@ -67,6 +67,7 @@ typedef struct {
     uint64_t tri_tests;       /* renderer.cc:137,305,311 */
     uint64_t slab_tests;      /* collision_ray_aabb calls (octree.cc:195) */
     uint64_t primary_rays, secondary_rays, shadow_rays;
+    uint64_t slab_tests_any, tri_tests_any; /* the part of slab_tests / tri_tests spent in is_shadowed */
 } orc_stats;
 
 typedef struct {
