@@ -152,8 +152,8 @@ typedef struct rt_render_stats {
     uint64_t primary_rays, secondary_rays, shadow_rays; /* each is one Search-equivalent query */
     uint64_t rays;                /* sum of the three */
     uint32_t levels;              /* recursion levels that had work */
-    float ms_closest, ms_shade, ms_resolve, ms_total; /* device time by kernel class (HIP events) */
-    uint32_t launches_closest, launches_shade;
+    float ms_closest, ms_shadow, ms_shade, ms_total;  /* device time by kernel class (HIP events) */
+    uint32_t launches_closest, launches_shadow, launches_shade;
 } rt_render_stats;
 
 /* Renderer::RenderScene's hot loop (src/Renderer/renderer.cc:37-52) on the device: primary rays

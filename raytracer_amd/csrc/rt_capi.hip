@@ -64,6 +64,7 @@ struct Level {
     DevBuf<float> hit_t;
     DevBuf<int32_t> hit_tri;
     DevBuf<uint32_t> work;
+    DevBuf<uint32_t> vis;  // visibility bits of the level's shadow samples
     uint32_t n = 0;
     hipError_t reserve(uint32_t count, bool need_rays) {
         hipError_t e;
@@ -74,7 +75,7 @@ struct Level {
         return work.reserve(count);
     }
     void release() {
-        rays.release(); out.release(); hit_t.release(); hit_tri.release(); work.release();
+        rays.release(); out.release(); hit_t.release(); hit_tri.release(); work.release(); vis.release();
     }
 };
 
@@ -103,7 +104,7 @@ struct rt_ads {
     uint32_t* h_counters = nullptr;
     DevBuf<float> d_accum, d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
-    hipEvent_t ev[2 + 4 * kMaxTimed] = {};
+    hipEvent_t ev[2 + 6 * kMaxTimed] = {};
     bool events_ready = false;
     rt_query_stats q{};
 };
@@ -415,7 +416,8 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(k_trace_closest, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, cull, d_t, d_tri);
+    if (cull) hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
+    else hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -449,7 +451,8 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(k_trace_any, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, cull, d_out);
+    if (cull) hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out);
+    else hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
@@ -639,10 +642,11 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     if (c->samples_per_pixel > 1) { HIP_TRY(a->d_accum.reserve((size_t)n0 * 3)); }
 
     rt_render_stats st{};
-    int n_timed_closest = 0, n_timed_shade = 0;
+    int n_timed_closest = 0, n_timed_shade = 0, n_timed_shadow = 0;
     hipEvent_t* ev_total = a->ev;
     hipEvent_t* ev_closest = a->ev + 2;
     hipEvent_t* ev_shade = a->ev + 2 + 2 * kMaxTimed;
+    hipEvent_t* ev_shadow = a->ev + 2 + 4 * kMaxTimed;
     HIP_TRY(hipEventRecord(ev_total[0], stream));
     const dim3 block(256);
     for (int s = 0; s < c->samples_per_pixel && n0 > 0; ++s) {
@@ -657,7 +661,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const dim3 grid((n + 255) / 256);
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            hipLaunchKernelGGL(k_closest, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
+            if (F.cull) hipLaunchKernelGGL(k_closest<true>, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
+            else hipLaunchKernelGGL(k_closest<false>, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
                 HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream));
@@ -680,10 +685,29 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 next_cap = (uint32_t)want;
             }
             const dim3 grid_s((n_work + 255) / 256);
+            const uint32_t words = (uint32_t)((std::max(c->samples_per_triangle, 1) + 31) / 32);
+            const bool lit = c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG;
+            if (lit && a->n_lights > 0 && c->samples_per_triangle > 0) {
+                HIP_TRY(lv.vis.reserve((size_t)n_work * a->n_lights * words));
+                const bool timed_a = n_timed_shadow < kMaxTimed;
+                if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
+                if (F.cull)
+                    hipLaunchKernelGGL(k_shadow<true>, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p,
+                                       lv.vis.p, words, cnt);
+                else
+                    hipLaunchKernelGGL(k_shadow<false>, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p,
+                                       lv.vis.p, words, cnt);
+                HIP_TRY(hipGetLastError());
+                if (timed_a) {
+                    HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream));
+                    ++n_timed_shadow;
+                }
+                st.launches_shadow++;
+            }
             const bool timed_s = n_timed_shade < kMaxTimed;
             if (timed_s) { HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade], stream)); }
-            hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.out.p, next_rays,
-                               next_cap, cnt);
+            hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words,
+                               lv.out.p, next_rays, next_cap, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_s) {
                 HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade + 1], stream));
@@ -732,6 +756,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         HIP_TRY(hipEventElapsedTime(&ms, ev_shade[2 * k], ev_shade[2 * k + 1]));
         st.ms_shade += ms;
     }
+    for (int k = 0; k < n_timed_shadow; ++k) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev_shadow[2 * k], ev_shadow[2 * k + 1]));
+        st.ms_shadow += ms;
+    }
     st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
     a->q.search_calls += st.rays;
     a->q.closest_rays += st.primary_rays + st.secondary_rays;
@@ -765,8 +793,12 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
         d_tri = (int32_t*)(a->d_io.p + npix * 4);
     }
     const dim3 block(256), grid((n0 + 255) / 256);
-    hipLaunchKernelGGL(k_closest, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
-                       lv.work.p, a->d_counters.p);
+    if (F.cull)
+        hipLaunchKernelGGL(k_closest<true>, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p,
+                           lv.out.p, lv.work.p, a->d_counters.p);
+    else
+        hipLaunchKernelGGL(k_closest<false>, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p,
+                           lv.out.p, lv.work.p, a->d_counters.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());

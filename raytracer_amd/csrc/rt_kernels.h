@@ -4,8 +4,10 @@
 //   k_trace_closest / k_trace_any : batched Search + closest-hit / any-hit loops for caller-supplied rays
 //   k_closest                     : one recursion level of the renderer: ray generation (level 0) or queue
 //                                   read, Search + closest hit, compaction of the hits into a work list
-//   k_shade                       : per hit: local illumination with area-light shadow samples (any-hit
-//                                   traversals), recursion gate, reflection / refraction ray construction
+//   k_shadow                      : the any-hit pass: per hit, every area-light shadow sample of every light ->
+//                                   one visibility bit each
+//   k_shade                       : per hit: local illumination from the visibility bits, recursion gate,
+//                                   reflection / refraction ray construction
 //   k_resolve / k_resolve_pixels  : bottom-up evaluation of the recursion tree in the reference's order
 //   k_search_count / k_search_fill: Ads::Search restated (breadth-first candidate lists)
 #pragma once
@@ -119,8 +121,9 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // ---- batched queries for caller-supplied rays --------------------------------------------------------------------
 
+template <bool CULL>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
-                                                       uint64_t n, int cull, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
+                                                       uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -129,15 +132,16 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
         d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     }
     HitState h;
-    traverse<false>(T, valid, o, d, cull != 0, 0.0f, h);
+    traverse<false, CULL>(T, valid, o, d, 0.0f, h);
     if (valid) {
         out_t[i] = h.t;
         out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
     }
 }
 
+template <bool CULL>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
-                                                   uint64_t n, int cull, uint8_t* __restrict__ out) {
+                                                   uint64_t n, uint8_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const float dist = length(pl);
     const f3 d = normalize(pl);
     HitState h;
-    traverse<true>(T, valid, p, d, cull != 0, dist, h);
+    traverse<true, CULL>(T, valid, p, d, dist, h);
     if (valid) out[i] = h.found ? 1 : 0;
 }
 
@@ -181,6 +185,7 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 }
 
 // Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
+template <bool CULL>
 __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint
     uint32_t pixel, node_id;
     load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
     HitState h;
-    traverse<false>(S.tree, valid, o, d, F.cull != 0, 0.0f, h);
+    traverse<false, CULL>(S.tree, valid, o, d, 0.0f, h);
     const bool hit = valid && !(h.t == RT_INF);
     if (valid) {
         hit_t[i] = h.t;
@@ -220,12 +225,80 @@ __device__ __forceinline__ f3 interpolate_normal(const LeafTri& g, const float* 
     return normalize(((n0 * u) + (n1 * v)) + (n2 * w));
 }
 
+// Area-light sample point (src/triangle.h:42-52) for (light l, sample s) of the path node whose generator
+// prefix is `pre`.
+__device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint32_t l, uint32_t s) {
+    const float r1 = u31_to_float(rng_finish(pre, l, s, 0));
+    const float r2 = u31_to_float(rng_finish(pre, l, s, 1));
+    const float uu = (r1 + r2 > 1.0f) ? 1.0f - r1 : r1;
+    const float vv = (r1 + r2 > 1.0f) ? 1.0f - r2 : r2;
+    const f3 la = mk(L.a[0], L.a[1], L.a[2]), le1 = mk(L.e1[0], L.e1[1], L.e1[2]), le2 = mk(L.e2[0], L.e2[1], L.e2[2]);
+    return (la + (le1 * uu)) + (le2 * vv);
+}
+
+// The any-hit pass: every shadow / area-light ray of every hit of one level (renderer.cc:217-219, 288-313).
+// One hit per lane; the lane walks its lights x samples in the reference's order, so the 64 rays a wave
+// traverses together at any moment are the same (light, sample) of 64 neighbouring hits.  The result is one
+// visibility bit per (light, sample): vis[(j * n_lights + l) * words + s / 32] bit s % 32 = 1 if not shadowed.
+template <bool CULL>
+__global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                                const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
+                                                const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
+                                                uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_work = counters[CNT_WORK];
+    const bool active = j < n_work;
+    uint32_t i = 0;
+    if (active) i = work[j];
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
+    valid = valid && active;
+    float t = 0.0f;
+    int32_t light_eq = -1;
+    if (valid) {
+        t = hit_t[i];
+        light_eq = S.tri_shade[hit_tri[i]].light_eq;
+    }
+    const f3 P = o + (d * t);  // renderer.cc:146
+    const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
+    uint32_t shadow_rays = 0;  // wave-uniform
+    bool live = valid;          // still inside render_local_ilumination's light loop
+    for (uint32_t l = 0; l < S.n_lights; ++l) {
+        if (light_eq == (int32_t)l) live = false;  // renderer.cc:212-214: the hit triangle is this light
+        if (ballot64(live) == 0) break;
+        const LightDev L = S.lights[l];
+        uint32_t bits = 0;
+        for (int s = 0; s < F.spt; ++s) {
+            const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
+            // renderer.cc:289-290
+            const f3 to_l = p_l - P;
+            const float dist = length(to_l);
+            const f3 d_l = normalize(to_l);
+            HitState h;
+            shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
+            traverse<true, CULL>(S.tree, live, P, d_l, dist, h);
+            if (!h.found) bits |= 1u << (s & 31);
+            if ((s & 31) == 31 || s + 1 == F.spt) {
+                if (live) vis[((size_t)j * S.n_lights + l) * words + (uint32_t)(s >> 5)] = bits;
+                bits = 0;
+            }
+        }
+    }
+    if (__lane_id() == 0 && shadow_rays) {
+        const uint32_t old = atomicAdd(&counters[CNT_SHADOW_LO], shadow_rays);
+        if (old + shadow_rays < old) atomicAdd(&counters[CNT_SHADOW_HI], 1u);
+    }
+}
+
 // Local illumination + recursion gate + secondary ray construction for every hit of one level
-// (renderer.cc:144-192, 202-335).
+// (renderer.cc:144-192, 202-335); the visibility of each light sample comes from k_shadow.
 __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
-                                               const uint32_t* __restrict__ work, NodeOut* __restrict__ out, RayRec* __restrict__ next,
-                                               uint32_t next_cap, uint32_t* __restrict__ counters) {
+                                               const uint32_t* __restrict__ work, const uint32_t* __restrict__ vis, uint32_t words,
+                                               NodeOut* __restrict__ out, RayRec* __restrict__ next, uint32_t next_cap,
+                                               uint32_t* __restrict__ counters) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_work = counters[CNT_WORK];
     const bool active = j < n_work;
@@ -251,61 +324,50 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
     const f3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
 
     f3 col = mk(0, 0, 0);
-    uint32_t shadow_rays = 0;  // wave-uniform
     if (F.render_type == 0) {  // renderer.cc:197-200
         const float g = 1.0f - (std_min(t, 1.5f * F.max_distance) / (1.5f * F.max_distance));
         col = col + mk(g, g, g);
     } else if (F.render_type == 1) {
         col = col + diffuse;
-    } else {  // renderer.cc:202-247
+    } else if (valid) {  // renderer.cc:202-247
         const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
-        bool live = valid;          // still inside render_local_ilumination's light loop
         f3 final_c = mk(0, 0, 0);
         for (uint32_t l = 0; l < S.n_lights; ++l) {
             const LightDev L = S.lights[l];
-            if (live && ts.light_eq == (int32_t)l) {  // renderer.cc:212-214: the hit triangle is this light
-                final_c = mk(L.emission[0], L.emission[1], L.emission[2]);
-                live = false;
-            }
-            if (ballot64(live) == 0) break;
-            const f3 la = mk(L.a[0], L.a[1], L.a[2]), le1 = mk(L.e1[0], L.e1[1], L.e1[2]), le2 = mk(L.e2[0], L.e2[1], L.e2[2]);
-            const f3 n_l = mk(L.n[0], L.n[1], L.n[2]);
             const f3 emission = mk(L.emission[0], L.emission[1], L.emission[2]);
+            if (ts.light_eq == (int32_t)l) {  // renderer.cc:212-214
+                final_c = emission;
+                break;
+            }
+            const f3 n_l = mk(L.n[0], L.n[1], L.n[2]);
             f3 acc = mk(0, 0, 0);
+            uint32_t bits = 0;
             for (int s = 0; s < F.spt; ++s) {
-                // src/triangle.h:42-52
-                const float r1 = u31_to_float(rng_finish(pre, l, (uint32_t)s, 0));
-                const float r2 = u31_to_float(rng_finish(pre, l, (uint32_t)s, 1));
-                const float uu = (r1 + r2 > 1.0f) ? 1.0f - r1 : r1;
-                const float vv = (r1 + r2 > 1.0f) ? 1.0f - r2 : r2;
-                const f3 p_l = (la + (le1 * uu)) + (le2 * vv);
-                // renderer.cc:288-313
+                if ((s & 31) == 0) bits = vis[((size_t)j * S.n_lights + l) * words + (uint32_t)(s >> 5)];
+                if (!((bits >> (s & 31)) & 1u)) continue;  // shadowed
+                const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
+                // renderer.cc:220-240
                 const f3 to_l = p_l - P;
                 const float dist = length(to_l);
                 const f3 d_l = normalize(to_l);
-                HitState h;
-                shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
-                traverse<true>(S.tree, live, P, d_l, F.cull != 0, dist, h);
-                if (live && !h.found) {  // renderer.cc:220-240
-                    const float w = (L.area * std_max(0.0f, dot(n_l, -d_l))) / ((float)F.spt * dist * dist + kEps);
-                    const f3 I_l = emission * w;
-                    const f3 d_v = normalize(F.cam_pos - P);
-                    const f3 I_a = I_l * mk(0, 0, 0);
-                    const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));
-                    f3 c;
-                    if (F.render_type == 2) {  // renderer.cc:249-267
-                        const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
-                        const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
-                        c = ((I_a + I_d) + I_s) + mk(m.emission[0], m.emission[1], m.emission[2]);
-                    } else {  // renderer.cc:269-286
-                        const f3 d_h = normalize(d_l + d_v);
-                        const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(N, d_h)), m.shininess);
-                        c = (I_a + I_d) + I_s;
-                    }
-                    acc = acc + c;
+                const float w = (L.area * std_max(0.0f, dot(n_l, -d_l))) / ((float)F.spt * dist * dist + kEps);
+                const f3 I_l = emission * w;
+                const f3 d_v = normalize(F.cam_pos - P);
+                const f3 I_a = I_l * mk(0, 0, 0);
+                const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));
+                f3 c;
+                if (F.render_type == 2) {  // renderer.cc:249-267
+                    const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
+                    const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
+                    c = ((I_a + I_d) + I_s) + mk(m.emission[0], m.emission[1], m.emission[2]);
+                } else {  // renderer.cc:269-286
+                    const f3 d_h = normalize(d_l + d_v);
+                    const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(N, d_h)), m.shininess);
+                    c = (I_a + I_d) + I_s;
                 }
+                acc = acc + c;
             }
-            if (live) final_c = final_c + acc;
+            final_c = final_c + acc;
         }
         col = col + final_c;
     }
@@ -359,10 +421,6 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
         r.parent = i; r.pixel = pixel; r.node_id = node_id * 2 + 1;
         r.pad[0] = r.pad[1] = r.pad[2] = 0;
         next[sT] = r;
-    }
-    if (__lane_id() == 0 && shadow_rays) {
-        const uint32_t old = atomicAdd(&counters[CNT_SHADOW_LO], shadow_rays);
-        if (old + shadow_rays < old) atomicAdd(&counters[CNT_SHADOW_HI], 1u);
     }
 }
 

@@ -49,23 +49,27 @@ __device__ __forceinline__ int write_lane(int v, int idx, int old) { return ((in
 
 // Moeller-Trumbore exactly as src/collision_detection.h:12-68: same operation order, the same
 // comparisons (so NaNs fall through the same way), 1/d as a correctly rounded division.
-// Returns +inf on a miss.
-__device__ __forceinline__ float ray_triangle(f3 o, f3 s, f3 a, f3 e1, f3 e2, bool cull) {
+// Written without per-lane branches: every lane of the wave computes every stage, `ok` carries the
+// lanes that are still inside the triangle, and the only branches are wave-uniform ("no lane is left").
+// Returns the lanes that hit; t is valid for them.
+template <bool CULL>
+__device__ __forceinline__ bool ray_triangle(bool mine, f3 o, f3 s, f3 a, f3 e1, f3 e2, float& t) {
+    t = RT_INF;
     const f3 p = cross(s, e2);
     const float d = dot(e1, p);
-    const bool reject = cull ? (d < kEps) : (fabsf(d) < kEps);
-    float t = RT_INF;
-    if (!reject) {
-        const float d_inv = 1.0f / d;
-        const f3 q = o - a;
-        const float u = d_inv * dot(q, p);
-        if (!(u < 0.0f || u > 1.0f)) {
-            const f3 w = cross(q, e1);
-            const float v = d_inv * dot(w, s);
-            if (!(v < 0.0f || (u + v) > 1.0f)) t = d_inv * dot(e2, w);
-        }
-    }
-    return t;
+    bool ok = mine && !(CULL ? (d < kEps) : (fabsf(d) < kEps));
+    if (ballot64(ok) == 0) return false;
+    const float d_inv = 1.0f / d;
+    const f3 q = o - a;
+    const float u = d_inv * dot(q, p);
+    ok = ok && !(u < 0.0f || u > 1.0f);
+    if (ballot64(ok) == 0) return false;
+    const f3 w = cross(q, e1);
+    const float v = d_inv * dot(w, s);
+    ok = ok && !(v < 0.0f || (u + v) > 1.0f);
+    if (ballot64(ok) == 0) return false;
+    t = d_inv * dot(e2, w);
+    return ok;
 }
 
 // Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the
@@ -101,9 +105,9 @@ struct HitState {
 };
 
 // Tests the triangles of leaf slots [begin, begin+count) for the lanes with `mine` set.
-template <bool ANY>
-__device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, bool mine, f3 o, f3 d, bool cull,
-                                           float t_limit, HitState& h) {
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, bool mine, f3 o, f3 d, float t_limit,
+                                           HitState& h) {
     cfloat_p base = as_const_f(T.slots);
     for (uint32_t k = 0; k < count; ++k) {
         const uint32_t slot = begin + k;
@@ -112,39 +116,34 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
         const f3 e1 = mk(r[3], r[4], r[5]);
         const f3 e2 = mk(r[6], r[7], r[8]);
         const uint32_t tri = __float_as_uint(r[9]);
-        if (mine) {
-            const float t = ray_triangle(o, d, a, e1, e2, cull);
-            if (!(t == RT_INF || t < kEps)) {  // renderer.cc:126 / :298
-                if (ANY) {
-                    if (t < t_limit) h.found = true;  // renderer.cc:302
-                } else {
-                    // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
-                    // smaller global slot.
-                    if (t < h.t || (t == h.t && slot < h.slot)) {
-                        h.t = t;
-                        h.slot = slot;
-                        h.tri = tri;
-                    }
-                }
-            }
-        }
+        float t;
+        bool hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
+        hit = hit && !(t == RT_INF || t < kEps);  // renderer.cc:126 / :298
         if (ANY) {
+            h.found = h.found || (hit && t < t_limit);  // renderer.cc:302
             mine = mine && !h.found;
             if (ballot64(mine) == 0) break;
+        } else {
+            // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
+            // smaller global slot.
+            const bool better = hit && (t < h.t || (t == h.t && slot < h.slot));
+            h.t = better ? t : h.t;
+            h.slot = better ? slot : h.slot;
+            h.tri = better ? tri : h.tri;
         }
     }
 }
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
-template <bool ANY>
-__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, bool cull, float t_limit, HitState& h) {
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
     h.tri = 0xffffffffu;
     h.found = false;
     if (T.root_info1 == 0) return;  // empty tree
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
-        leaf_tests<ANY>(T, T.root_info0, T.root_info1, valid, o, d, cull, t_limit, h);
+        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, valid, o, d, t_limit, h);
         return;
     }
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
@@ -204,7 +203,7 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
                 }
                 ++sp;
             } else {
-                leaf_tests<ANY>(T, info0, info1, pass, o, d, cull, t_limit, h);
+                leaf_tests<ANY, CULL>(T, info0, info1, pass, o, d, t_limit, h);
                 if (ANY) {
                     mine = mine && !h.found;
                     if (ballot64(mine) == 0) break;
