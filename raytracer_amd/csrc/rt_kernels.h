@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const f3 d = normalize(pl);
     HitState h;
     traverse<true, CULL>(T, valid, p, d, dist, h);
-    if (valid) out[i] = h.found ? 1 : 0;
+    if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
 // ---- renderer level kernels ------------------------------------------------------------------------------------
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
             HitState h;
             shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
             traverse<true, CULL>(S.tree, live, P, d_l, dist, h);
-            if (!h.found) bits |= 1u << (s & 31);
+            if (!lane_of(h.found)) bits |= 1u << (s & 31);
             if ((s & 31) == 31 || s + 1 == F.spt) {
                 if (live) vis[((size_t)j * S.n_lights + l) * words + (uint32_t)(s >> 5)] = bits;
                 bits = 0;

@@ -1,12 +1,17 @@
 // rt_traverse.h -- wave64 octree traversal + ray/triangle test for gfx950 (device only).
 //
 // One ray per lane, 64 rays per wavefront, traversed TOGETHER: the wave walks the union of the
-// nodes its rays reach, and each stack entry carries the 64-bit ballot of the lanes that reached
+// nodes its rays reach, and each stack entry carries the 64-bit mask of the lanes that reached
 // it.  Because the node being worked on is the same for every lane, node records and triangle
 // records are fetched with scalar loads (s_load through the constant cache) and feed the VALU as
 // SGPR operands; no vector memory instruction and no LDS is needed inside the loop.  The stack
 // itself lives in registers: entry i of the wave-uniform stack is stored in lane i of a VGPR
 // (written with a lane-select, read with v_readlane), two VGPRs per field for up to 128 entries.
+//
+// Lane predicates are kept as explicit 64-bit masks in scalar registers: every float comparison is
+// turned into a mask by a ballot (which is just the v_cmp result), masks are combined with scalar
+// logic, and the only branches are wave-uniform "no lane is left" tests.  All lanes execute every
+// arithmetic stage; lanes that are not in the mask compute garbage that is never selected.
 //
 // The set of (ray, triangle) tests performed is exactly the candidate set of the reference's
 // Octree::Search (src/ADS/Octree/octree.cc:173-207 of the reference): a triangle reference is
@@ -36,39 +41,38 @@ struct DevOctree {
 
 typedef const RT_CONST float* cfloat_p;
 typedef const RT_CONST uint32_t* cu32_p;
+typedef uint64_t lanemask;
 
 __device__ __forceinline__ cfloat_p as_const_f(const void* p) { return (cfloat_p)(uintptr_t)p; }
 __device__ __forceinline__ cu32_p as_const_u(const void* p) { return (cu32_p)(uintptr_t)p; }
 
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ lanemask ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_of(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // Writes the wave-uniform value v into lane `idx` of the per-lane register `old` (a v_writelane; this
 // compiler exposes no builtin for it, and a compare + select is what it lowers to anyway).
 __device__ __forceinline__ int write_lane(int v, int idx, int old) { return ((int)__lane_id() == idx) ? v : old; }
 
 // Moeller-Trumbore exactly as src/collision_detection.h:12-68: same operation order, the same
 // comparisons (so NaNs fall through the same way), 1/d as a correctly rounded division.
-// Written without per-lane branches: every lane of the wave computes every stage, `ok` carries the
-// lanes that are still inside the triangle, and the only branches are wave-uniform ("no lane is left").
-// Returns the lanes that hit; t is valid for them.
+// Returns the lanes of `mine` whose ray hits the triangle with a usable distance, i.e. that pass
+// the reference's `t == infinity || t < epsilon` filter too (renderer.cc:126 / :298); t is valid for them.
 template <bool CULL>
-__device__ __forceinline__ bool ray_triangle(bool mine, f3 o, f3 s, f3 a, f3 e1, f3 e2, float& t) {
-    t = RT_INF;
+__device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a, f3 e1, f3 e2, float& t) {
     const f3 p = cross(s, e2);
     const float d = dot(e1, p);
-    bool ok = mine && !(CULL ? (d < kEps) : (fabsf(d) < kEps));
-    if (ballot64(ok) == 0) return false;
+    lanemask ok = mine & ~ballot64(CULL ? (d < kEps) : (fabsf(d) < kEps));
+    if (ok == 0) return 0;
     const float d_inv = 1.0f / d;
     const f3 q = o - a;
     const float u = d_inv * dot(q, p);
-    ok = ok && !(u < 0.0f || u > 1.0f);
-    if (ballot64(ok) == 0) return false;
+    ok &= ~(ballot64(u < 0.0f) | ballot64(u > 1.0f));
+    if (ok == 0) return 0;
     const f3 w = cross(q, e1);
     const float v = d_inv * dot(w, s);
-    ok = ok && !(v < 0.0f || (u + v) > 1.0f);
-    if (ballot64(ok) == 0) return false;
+    ok &= ~(ballot64(v < 0.0f) | ballot64((u + v) > 1.0f));
+    if (ok == 0) return 0;
     t = d_inv * dot(e2, w);
+    ok &= ~(ballot64(t == RT_INF) | ballot64(t < kEps));
     return ok;
 }
 
@@ -98,15 +102,15 @@ __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, floa
 }
 
 struct HitState {
-    float t;        // closest: best t so far (+inf = none)
-    uint32_t slot;  // closest: global leaf slot of the winner
-    uint32_t tri;   // closest: its triangle index
-    bool found;     // any-hit: occluder found
+    float t;         // closest: best t so far (+inf = none)
+    uint32_t slot;   // closest: global leaf slot of the winner
+    uint32_t tri;    // closest: its triangle index
+    lanemask found;  // any-hit: lanes that have found an occluder (wave-uniform)
 };
 
-// Tests the triangles of leaf slots [begin, begin+count) for the lanes with `mine` set.
+// Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.
 template <bool ANY, bool CULL>
-__device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, bool mine, f3 o, f3 d, float t_limit,
+__device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, lanemask mine, f3 o, f3 d, float t_limit,
                                            HitState& h) {
     cfloat_p base = as_const_f(T.slots);
     for (uint32_t k = 0; k < count; ++k) {
@@ -115,21 +119,23 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
         const f3 a = mk(r[0], r[1], r[2]);
         const f3 e1 = mk(r[3], r[4], r[5]);
         const f3 e2 = mk(r[6], r[7], r[8]);
-        const uint32_t tri = __float_as_uint(r[9]);
-        float t;
-        bool hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
-        hit = hit && !(t == RT_INF || t < kEps);  // renderer.cc:126 / :298
+        float t = RT_INF;
+        const lanemask hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
+        if (hit == 0) continue;
         if (ANY) {
-            h.found = h.found || (hit && t < t_limit);  // renderer.cc:302
-            mine = mine && !h.found;
-            if (ballot64(mine) == 0) break;
+            h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+            mine &= ~h.found;
+            if (mine == 0) break;
         } else {
             // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
             // smaller global slot.
-            const bool better = hit && (t < h.t || (t == h.t && slot < h.slot));
-            h.t = better ? t : h.t;
-            h.slot = better ? slot : h.slot;
-            h.tri = better ? tri : h.tri;
+            const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
+            if (better == 0) continue;
+            const uint32_t tri = __float_as_uint(r[9]);
+            const bool b = lane_of(better);
+            h.t = b ? t : h.t;
+            h.slot = b ? slot : h.slot;
+            h.tri = b ? tri : h.tri;
         }
     }
 }
@@ -140,46 +146,22 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     h.t = RT_INF;
     h.slot = 0xffffffffu;
     h.tri = 0xffffffffu;
-    h.found = false;
-    if (T.root_info1 == 0) return;  // empty tree
+    h.found = 0;
+    const lanemask all = ballot64(valid);
+    if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
-        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, valid, o, d, t_limit, h);
+        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, all, o, d, t_limit, h);
         return;
     }
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
-    const uint32_t lane = __lane_id();
-    const uint32_t lane_bit = 1u << (lane & 31);
-    const bool upper = lane >= 32;
 
     // Register-resident wave-uniform stack: entry i lives in lane (i & 63) of stack register (i >> 6).
     int s_node0 = 0, s_node1 = 0, s_mlo0 = 0, s_mlo1 = 0, s_mhi0 = 0, s_mhi1 = 0;
     int sp = 0;
-    {
-        const uint64_t m = ballot64(valid);
-        if (m == 0) return;
-        s_node0 = write_lane((int)T.root_info0, 0, s_node0);
-        s_mlo0 = write_lane((int)(uint32_t)m, 0, s_mlo0);
-        s_mhi0 = write_lane((int)(uint32_t)(m >> 32), 0, s_mhi0);
-        sp = 1;
-    }
+    uint32_t ni = T.root_info0;
+    lanemask mine = all;
     cu32_p nodes = as_const_u(T.nodes);
-    while (sp > 0) {
-        --sp;
-        uint32_t ni, mlo, mhi;
-        if (sp < 64) {
-            ni = (uint32_t)__builtin_amdgcn_readlane(s_node0, sp);
-            mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo0, sp);
-            mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi0, sp);
-        } else {
-            ni = (uint32_t)__builtin_amdgcn_readlane(s_node1, sp - 64);
-            mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo1, sp - 64);
-            mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi1, sp - 64);
-        }
-        bool mine = ((upper ? mhi : mlo) & lane_bit) != 0;
-        if (ANY) {
-            mine = mine && !h.found;
-            if (ballot64(mine) == 0) continue;
-        }
+    for (;;) {
         cu32_p rec = nodes + (size_t)ni * 64;
 #pragma unroll 1
         for (int c = 0; c < 8; ++c) {
@@ -188,8 +170,7 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
             const uint32_t info0 = rec[48 + c * 2];
             const float bx0 = __uint_as_float(rec[c * 6 + 0]), by0 = __uint_as_float(rec[c * 6 + 1]), bz0 = __uint_as_float(rec[c * 6 + 2]);
             const float bx1 = __uint_as_float(rec[c * 6 + 3]), by1 = __uint_as_float(rec[c * 6 + 4]), bz1 = __uint_as_float(rec[c * 6 + 5]);
-            const bool pass = mine && ray_box(o, inv, bx0, by0, bz0, bx1, by1, bz1);
-            const uint64_t pm = ballot64(pass);
+            const lanemask pm = mine & ballot64(ray_box(o, inv, bx0, by0, bz0, bx1, by1, bz1));
             if (pm == 0) continue;
             if (info1 & kChildInternal) {
                 if (sp < 64) {
@@ -203,13 +184,35 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
                 }
                 ++sp;
             } else {
-                leaf_tests<ANY, CULL>(T, info0, info1, pass, o, d, t_limit, h);
+                leaf_tests<ANY, CULL>(T, info0, info1, pm, o, d, t_limit, h);
                 if (ANY) {
-                    mine = mine && !h.found;
-                    if (ballot64(mine) == 0) break;
+                    mine &= ~h.found;
+                    if (mine == 0) break;
                 }
             }
         }
+        // pop the next internal node that still has a live lane
+        bool got = false;
+        while (sp > 0) {
+            --sp;
+            uint32_t mlo, mhi;
+            if (sp < 64) {
+                ni = (uint32_t)__builtin_amdgcn_readlane(s_node0, sp);
+                mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo0, sp);
+                mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi0, sp);
+            } else {
+                ni = (uint32_t)__builtin_amdgcn_readlane(s_node1, sp - 64);
+                mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo1, sp - 64);
+                mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi1, sp - 64);
+            }
+            mine = ((lanemask)mhi << 32) | mlo;
+            if (ANY) mine &= ~h.found;
+            if (mine != 0) {
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
     }
 }
 
