@@ -302,6 +302,43 @@ void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
             }
         }
     }
+    // small-tree form
+    {
+        uint32_t n_leaves = 0;
+        for (const HostNode& n : t.nodes) n_leaves += n.leaf ? 1u : 0u;
+        const size_t n_tri = t.nodes[0].tri_count;
+        if (!t.nodes[0].leaf && n_leaves <= kFlatMaxLeaves && n_tri <= kFlatMaxTris) {
+            std::vector<uint32_t> ordinal(nn, 0);
+            uint32_t next = 0;
+            for (size_t i = 0; i < nn; ++i)
+                if (t.nodes[i].leaf) ordinal[i] = next++;
+            out.flat_tris.resize(n_tri);
+            for (size_t j = 0; j < n_tri; ++j) {
+                const float* p = positions + j * 9;
+                LeafTri& s = out.flat_tris[j];
+                s.ax = p[0]; s.ay = p[1]; s.az = p[2];
+                s.e1x = p[3] - p[0]; s.e1y = p[4] - p[1]; s.e1z = p[5] - p[2];
+                s.e2x = p[6] - p[0]; s.e2y = p[7] - p[1]; s.e2z = p[8] - p[2];
+                s.tri = (uint32_t)j;
+                s.pad0 = s.pad1 = 0;
+            }
+            for (size_t i = 0; i < nn; ++i) {
+                const HostNode& n = t.nodes[i];
+                if (!n.leaf) continue;
+                for (uint32_t k = 0; k < n.tri_count; ++k) out.flat_tris[t.pool[n.tri_begin + k]].pad0 |= 1u << ordinal[i];
+            }
+            out.flat_nodes = out.nodes;
+            for (size_t i = 0; i < nn; ++i) {
+                const HostNode& n = t.nodes[i];
+                if (n.leaf) continue;
+                NodeRec& r = out.flat_nodes[rec_of[i]];
+                for (int o = 0; o < 8; ++o) {
+                    const int32_t ci = n.child[o];
+                    if (ci >= 0 && t.nodes[ci].tri_count != 0 && t.nodes[ci].leaf) r.info[o][0] = ordinal[ci];
+                }
+            }
+        }
+    }
     if (t.nodes[0].leaf) {
         out.root_info[0] = 0;
         out.root_info[1] = t.nodes[0].tri_count;

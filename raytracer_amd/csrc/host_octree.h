@@ -52,6 +52,7 @@ struct alignas(16) LeafTri {
 static_assert(sizeof(LeafTri) == 48, "LeafTri must be 48 bytes");
 
 constexpr uint32_t kChildInternal = 0x80000000u;
+constexpr uint32_t kFlatMaxLeaves = 32, kFlatMaxTris = 1024;
 
 // One internal node.  info[o][1] == 0: octant o is null/empty (skipped before any box test,
 // octree.cc:195); info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0];
@@ -67,6 +68,11 @@ struct FlatOctree {
     std::vector<LeafTri> slots;  // leaf slots, breadth-first leaf order
     uint32_t root_info[2] = {0, 0};  // like NodeRec::info for the root (never box-tested, octree.cc:177)
     uint32_t max_stack = 0;          // deepest traversal stack any ray can need
+    // Small-tree form, filled when the tree has at most kFlatMaxLeaves leaves and kFlatMaxTris triangles:
+    // flat_nodes = nodes with leaf octants' info[0] = leaf ordinal; flat_tris[j] = triangle j with pad0 = the
+    // bit mask of the leaves that list it.
+    std::vector<NodeRec> flat_nodes;
+    std::vector<LeafTri> flat_tris;
 };
 
 struct TreeShape {

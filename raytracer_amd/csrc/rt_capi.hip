@@ -86,14 +86,15 @@ constexpr int kMaxTimed = 64;
 struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
-    bool built = false, shading_set = false, has_normals = false, branching = false;
+    bool built = false, shading_set = false, has_normals = false, branching = false, use_flat = true;
     uint64_t n_tri = 0;
     std::vector<float> positions;
     HostOctree host;
     FlatOctree flat;
     TreeShape shape;
     DevBuf<NodeRec> d_nodes;
-    DevBuf<LeafTri> d_slots, d_tri_geom;
+    DevBuf<LeafTri> d_slots, d_tri_geom, d_flat_tris;
+    DevBuf<NodeRec> d_flat_nodes;
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
     DevBuf<MatDev> d_mats;
@@ -119,6 +120,9 @@ DevOctree dev_tree(const rt_ads* a) {
     t.root_info1 = a->host.empty ? 0u : a->flat.root_info[1];
     t.n_nodes = (uint32_t)a->flat.nodes.size();
     t.n_slots = (uint32_t)a->flat.slots.size();
+    t.flat_nodes = a->d_flat_nodes.p;
+    t.flat_tris = a->d_flat_tris.p;
+    t.n_flat_tris = a->use_flat ? (uint32_t)a->flat.flat_tris.size() : 0u;
     return t;
 }
 
@@ -251,7 +255,7 @@ void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
     a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
-    a->d_mats.release(); a->d_lights.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
+    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
     for (auto& l : a->levels) l.release();
     if (a->h_counters) (void)hipHostFree(a->h_counters);
     if (a->events_ready)
@@ -281,6 +285,13 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
         HIP_TRY(hipMemcpy(a->d_nodes.p, a->flat.nodes.data(), a->flat.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
     if (!a->flat.slots.empty())
         HIP_TRY(hipMemcpy(a->d_slots.p, a->flat.slots.data(), a->flat.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    if (!a->flat.flat_tris.empty()) {
+        HIP_TRY(a->d_flat_nodes.reserve(a->flat.flat_nodes.size()));
+        HIP_TRY(a->d_flat_tris.reserve(a->flat.flat_tris.size()));
+        HIP_TRY(hipMemcpy(a->d_flat_nodes.p, a->flat.flat_nodes.data(), a->flat.flat_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(a->d_flat_tris.p, a->flat.flat_tris.data(), a->flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    }
+    if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
     if (n) {
         std::vector<LeafTri> g(n);
         for (uint64_t i = 0; i < n; ++i) {

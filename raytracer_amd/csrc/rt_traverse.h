@@ -37,6 +37,12 @@ struct DevOctree {
     const LeafTri* slots;
     uint32_t root_info0, root_info1;
     uint32_t n_nodes, n_slots;
+    // Small-tree form (n_flat_tris > 0): at most 32 leaves.  flat_nodes = nodes with each leaf octant's info[0]
+    // replaced by the leaf's ordinal (breadth-first leaf order); flat_tris[j] = triangle j's geometry with the
+    // set of leaves that list it as a bit mask in pad0.
+    const NodeRec* flat_nodes;
+    const LeafTri* flat_tris;
+    uint32_t n_flat_tris;
 };
 
 typedef const RT_CONST float* cfloat_p;
@@ -103,7 +109,7 @@ __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, floa
 
 struct HitState {
     float t;         // closest: best t so far (+inf = none)
-    uint32_t slot;   // closest: global leaf slot of the winner
+    uint32_t slot;   // closest: global leaf slot of the winner (small-tree form: ordinal of its first reached leaf)
     uint32_t tri;    // closest: its triangle index
     lanemask found;  // any-hit: lanes that have found an occluder (wave-uniform)
 };
@@ -140,27 +146,56 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
     }
 }
 
-// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
+// Small-tree form of the leaf work.  `reach` holds, per lane, the set of leaves the lane's ray reaches (one bit
+// per leaf ordinal).  Instead of walking leaf after leaf -- which tests a triangle once per leaf that lists it and,
+// for a wave, once per leaf ANY lane reaches -- the wave walks the triangle array once: triangle j is a candidate
+// of a lane iff it is listed by a leaf the lane reaches.  The candidate SET per ray is unchanged, so any-hit
+// answers and closest distances are unchanged.  The reference's tie rule (first in candidate-list order) becomes:
+// smaller ordinal of the first reached leaf that lists the triangle, then smaller triangle index (leaf lists are
+// ascending); the loop runs in ascending j, so an equal-t later triangle wins only with a smaller first leaf.
 template <bool ANY, bool CULL>
-__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    h.t = RT_INF;
-    h.slot = 0xffffffffu;
-    h.tri = 0xffffffffu;
-    h.found = 0;
-    const lanemask all = ballot64(valid);
-    if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
-    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
-        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, all, o, d, t_limit, h);
-        return;
+__device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask alive, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
+    cfloat_p base = as_const_f(T.flat_tris);
+    const uint32_t n = T.n_flat_tris;
+    for (uint32_t j = 0; j < n; ++j) {
+        cfloat_p r = base + (size_t)j * 12;
+        const uint32_t lm = __float_as_uint(r[10]);
+        const lanemask need = alive & ballot64((reach & lm) != 0);
+        if (need == 0) continue;
+        const f3 a = mk(r[0], r[1], r[2]);
+        const f3 e1 = mk(r[3], r[4], r[5]);
+        const f3 e2 = mk(r[6], r[7], r[8]);
+        float t = RT_INF;
+        const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
+        if (hit == 0) continue;
+        if (ANY) {
+            h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+            alive &= ~h.found;
+            if (alive == 0) break;
+        } else {
+            const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);  // garbage on lanes outside `need`
+            const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
+            if (better == 0) continue;
+            const bool b = lane_of(better);
+            h.t = b ? t : h.t;
+            h.slot = b ? first_leaf : h.slot;
+            h.tri = b ? j : h.tri;
+        }
     }
+}
+
+// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
+template <bool ANY, bool CULL, bool FLAT>
+__device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
 
     // Register-resident wave-uniform stack: entry i lives in lane (i & 63) of stack register (i >> 6).
     int s_node0 = 0, s_node1 = 0, s_mlo0 = 0, s_mlo1 = 0, s_mhi0 = 0, s_mhi1 = 0;
     int sp = 0;
     uint32_t ni = T.root_info0;
+    uint32_t reach = 0;
     lanemask mine = all;
-    cu32_p nodes = as_const_u(T.nodes);
+    cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);
     for (;;) {
         cu32_p rec = nodes + (size_t)ni * 64;
 #pragma unroll 1
@@ -183,6 +218,8 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
                     s_mhi1 = write_lane((int)(uint32_t)(pm >> 32), sp - 64, s_mhi1);
                 }
                 ++sp;
+            } else if (FLAT) {
+                reach |= lane_of(pm) ? (1u << info0) : 0u;
             } else {
                 leaf_tests<ANY, CULL>(T, info0, info1, pm, o, d, t_limit, h);
                 if (ANY) {
@@ -214,6 +251,23 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
         }
         if (!got) break;
     }
+    if (FLAT) flat_tests<ANY, CULL>(T, all, reach, o, d, t_limit, h);
+}
+
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    h.t = RT_INF;
+    h.slot = 0xffffffffu;
+    h.tri = 0xffffffffu;
+    h.found = 0;
+    const lanemask all = ballot64(valid);
+    if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
+    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
+        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, all, o, d, t_limit, h);
+        return;
+    }
+    if (T.n_flat_tris) traverse_impl<ANY, CULL, true>(T, all, o, d, t_limit, h);
+    else traverse_impl<ANY, CULL, false>(T, all, o, d, t_limit, h);
 }
 
 }  // namespace rt

@@ -50,7 +50,8 @@ def random_rays(sc, n, seed):
     return o, d.astype(np.float32)
 
 
-@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3), ("original", 1000, 10)])
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3), ("original", 1000, 10),
+                                         ("original", 14, 3), ("original", 8, 2)])
 @pytest.mark.parametrize("cull", [True, False])
 def test_trace_closest(rt, orc, scenes, scene, mb, md, cull):
     sc = scenes[scene]
@@ -84,6 +85,34 @@ def test_trace_any(rt, orc, scenes, scene):
         got = g.trace_any(P, L, cull)
         assert np.array_equal(ref, got)
         assert 0 < ref.sum() < ref.size
+
+
+def test_small_tree_form_equals_general_form(rt, orc, scenes, monkeypatch):
+    """Trees with at most 32 leaves are traversed in a special form (one pass over the triangle array with
+    per-lane leaf-reach masks).  It must give the same hits as the general leaf-by-leaf traversal, ties included:
+    rays aimed exactly at shared vertices and edges produce equal-t candidates."""
+    sc = scenes["original"]
+    o1, d1 = random_rays(sc, 20000, 21)
+    verts = sc.pos.reshape(-1, 3)
+    rs = np.random.RandomState(4)
+    o2 = np.tile(np.asarray(CAMERAS["original"]["cam_pos"], np.float32), (4000, 1))
+    tri = sc.pos[rs.randint(0, sc.n_tri, 4000)]
+    w = rs.rand(4000, 1).astype(np.float32)
+    target = np.where(rs.rand(4000, 1) < 0.5, tri[:, 0], tri[:, 0] * w + tri[:, 1] * (1 - w))  # a vertex, or a point on an edge
+    d2 = (target - o2).astype(np.float32)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    for mb, md in ((16, 10), (14, 3)):
+        ot = orc.Octree(sc, mb, md)
+        for cull in (True, False):
+            t_ref, tri_ref = ot.trace_closest(o, d, cull)
+            monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "0")
+            g_small = build(rt, sc, mb, md)
+            monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+            g_general = build(rt, sc, mb, md)
+            for g in (g_small, g_general):
+                t, tri_ = g.trace_closest(o, d, cull)
+                assert np.array_equal(tri_, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+    assert len(verts) > 0
 
 
 @pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3)])
