@@ -220,3 +220,24 @@ def test_errors(rt, scenes):
         g.render(rt.make_render_config(fov=0.6, width=8, height=8, shading="smooth", **CAMERAS["original"]))
     with pytest.raises(RuntimeError, match="samples_per_pixel"):
         g.render(rt.make_render_config(fov=0.6, width=8, height=8, spp=0, **CAMERAS["original"]))
+
+
+def test_dropin_behind_reference_ads_interface(scenes, tmp_path):
+    """oracle/_ref/ads_dropin_test links the REFERENCE's own Octree sources and this build's GpuOctree subclass
+    (raytracer_amd/host/gpu_octree_ads.h) into one program and compares them through the reference's Ads
+    interface.  The binary is built where the reference checkout exists and travels with the tree."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ads_dropin_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ads_dropin_test not built (no reference checkout at build time)")
+    for name in ("original", "sphere"):
+        raw = tmp_path / f"{name}.raw"
+        pos = np.ascontiguousarray(scenes[name].pos, np.float32)
+        with open(raw, "wb") as f:
+            f.write(np.uint64(pos.shape[0]).tobytes())
+            f.write(pos.tobytes())
+        p = subprocess.run([exe, str(raw), "1500"], capture_output=True, text=True, timeout=100)
+        assert p.returncode == 0, p.stderr[-500:]
+        assert "DROPIN PASS" in p.stdout
