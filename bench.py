@@ -37,6 +37,14 @@ WORKLOADS = {
     "cornell_sphere_blinn_smooth_spp4_1080p": dict(
         scene="cornell_sphere", cam=CAM_SPHERE, width=1920, height=1080, spp=4, spt=32, render_type="blinn_phong",
         shading="smooth", cull=True, max_depth=10, cpu_rows=(540, 545)),
+    # configs[3]: 1,310,754 triangles (Cornell box + icosphere level 8), hard shadows, true aspect ratio
+    "synthetic_ico8_phong_4k": dict(
+        scene="synthetic:8", cam=CAM_ORIGINAL, width=3840, height=2160, spp=1, spt=1, render_type="phong",
+        shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160)),
+    # configs[4]: fuzzysampling + 32 light samples, 4K
+    "cornell_original_blinn_spp64_spt32_4k": dict(
+        scene="cornell_original", cam=CAM_ORIGINAL, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong",
+        shading="flat", cull=True, max_depth=10, cpu_rows=(1080, 1082)),
     # a small case for quick checks
     "cornell_original_blinn_spt4_256": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=256, height=256, spp=1, spt=4, render_type="blinn_phong",
@@ -77,31 +85,30 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
-    scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
+    if wl["scene"].startswith("synthetic:"):
+        from raytracer_amd.synthetic import cornell_with_icosphere
+        box = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", "cornell_original.npz"))
+        scene = cornell_with_icosphere(box, int(wl["scene"].split(":")[1]))
+    else:
+        scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
     ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=local_rank)
     ads.Build(scene.pos)
     ads.set_shading(scene.norm, scene.matid, scene.materials)
+    tree_stats = ads.tree_stats()
     W, H = wl["width"], wl["height"]
+    aspect = 1 if wl.get("aspect") == "true" else 0
     kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=wl["render_type"], shading=wl["shading"],
-              cull=wl["cull"], max_depth=wl["max_depth"], seed=42, **wl["cam"])
+              cull=wl["cull"], max_depth=wl["max_depth"], seed=42, aspect_mode=aspect, **wl["cam"])
     cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
 
-    bands = (H + 7) // 8
-    bands_pad = (bands + world - 1) // world * world
-    frame = torch.zeros((bands_pad * 8, W, 3), dtype=torch.float32, device="cuda")
+    from raytracer_amd import distributed as rd
+    frame = rd.alloc_frame(H, W, world, "cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    per_rank = bands_pad // world
-    parts = [torch.empty((per_rank, 8 * W * 3), dtype=torch.float32, device="cuda") for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather = rd.BandGather(H, W, rank, world, "cuda", dist)
 
     def step():
         _, st = ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
-        if world > 1:
-            mine = frame.view(bands_pad, 8 * W * 3)[rank::world].contiguous()
-            dist.gather(mine, parts, dst=0)
-            if rank == 0:
-                fv = frame.view(bands_pad, 8 * W * 3)
-                for r in range(world):
-                    fv[r::world] = parts[r]
+        gather(frame)  # framebuffer bands -> rank 0 (RCCL); no-op for one rank
         return st
 
     def fence():
@@ -151,7 +158,8 @@ def main():
             "dtype": "f32", "data": "synthetic camera over the Cornell-box scene dump (tests/golden/scenes); counter-based RNG",
             "config": {"workload": args.workload, "width": W, "height": H, "samples_per_pixel": wl["spp"],
                        "samples_per_triangle": wl["spt"], "render_type": wl["render_type"], "shading": wl["shading"],
-                       "octree": "max_triangles_per_BB=16,max_depth=10", "aspect_mode": "compat",
+                       "octree": "max_triangles_per_BB=16,max_depth=10", "aspect_mode": "true" if aspect else "compat",
+                       "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3),
                        "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)"},
         }
         # ---- CPU baseline + reference-work counts on a bounded sample of the same frame (rank 0, N = 1 only) ----

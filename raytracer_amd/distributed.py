@@ -1,0 +1,61 @@
+"""Image partition across ranks and the framebuffer gather (one process per GPU, torch.distributed).
+
+The image is cut into bands of 8 pixel rows (one row of 8x8 wavefront tiles).  Band b belongs to rank
+b % world; the scene is replicated; nothing is exchanged while rendering.  After rendering, each rank holds
+its bands inside a full-size frame buffer; `gather_bands` moves them to rank 0 with one collective
+(`torch.distributed.gather`: RCCL on GPUs, gloo on CPU) and interleaves them back into rank 0's frame.
+"""
+import torch
+
+BAND_ROWS = 8
+
+
+def num_bands(height):
+    return (height + BAND_ROWS - 1) // BAND_ROWS
+
+
+def padded_bands(height, world):
+    """Bands rounded up to a multiple of world so that every rank contributes an equal-size block."""
+    b = num_bands(height)
+    return (b + world - 1) // world * world
+
+
+def bands_of_rank(height, rank, world):
+    return list(range(rank, num_bands(height), world))
+
+
+def rows_of_rank(height, rank, world):
+    rows = []
+    for b in bands_of_rank(height, rank, world):
+        rows.extend(range(b * BAND_ROWS, min((b + 1) * BAND_ROWS, height)))
+    return rows
+
+
+def alloc_frame(height, width, world, device):
+    """Frame buffer with the row count padded to whole bands for every rank (the renderer only writes rows < height)."""
+    return torch.zeros((padded_bands(height, world) * BAND_ROWS, width, 3), dtype=torch.float32, device=device)
+
+
+class BandGather:
+    """Pre-allocated gather of the bands to rank 0."""
+
+    def __init__(self, height, width, rank, world, device, dist=None):
+        self.height, self.width, self.rank, self.world, self.dist = height, width, rank, world, dist
+        self.bands_pad = padded_bands(height, world)
+        self.row_floats = BAND_ROWS * width * 3
+        per_rank = self.bands_pad // world
+        self.parts = None
+        if world > 1 and rank == 0:
+            self.parts = [torch.empty((per_rank, self.row_floats), dtype=torch.float32, device=device) for _ in range(world)]
+
+    def __call__(self, frame):
+        """frame: alloc_frame(...) tensor holding this rank's bands.  On return rank 0's frame is complete."""
+        if self.world == 1:
+            return frame
+        fv = frame.view(self.bands_pad, self.row_floats)
+        mine = fv[self.rank::self.world].contiguous()
+        self.dist.gather(mine, self.parts, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                fv[r::self.world] = self.parts[r]
+        return frame

@@ -192,6 +192,38 @@ def test_render_matches_oracle(rt, orc, scenes, case):
         assert np.abs(q(img) - q(ref)).max() <= 1
 
 
+@pytest.mark.parametrize("levels,w,h,spt", [(5, 96, 96, 2), (8, 64, 64, 1)])
+def test_synthetic_icosphere_scene(rt, orc, levels, w, h, spt):
+    """The deep-tree workload (levels = 8: 1,310,754 triangles, 533,107 nodes, depth 10): primary hits, shadow rays
+    and the Phong image against the oracle at a size the oracle finishes in seconds, in true-aspect mode."""
+    import os
+    from conftest import GOLDEN
+    from raytracer_amd.scene import Scene
+    from raytracer_amd.synthetic import cornell_with_icosphere
+    s = cornell_with_icosphere(Scene.load_npz(os.path.join(GOLDEN, "scenes", "cornell_original.npz")), levels)
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    g.Build(s.pos)
+    g.set_shading(None, s.matid, s.materials)
+    osc = orc.Scene.from_arrays(s.pos, None, s.matid, s.materials)
+    ot = orc.Octree(osc, 16, 10)
+    cam = CAMERAS["original"]
+    kw = dict(fov=0.6, width=w, height=h, spt=spt, render_type="phong", shading="flat", **cam)
+    ref, ref_tri, ref_t, st = orc.render(osc, ot, orc.make_cfg(rng_mode=orc.RNG_COUNTER, aspect_mode=orc.ASPECT_TRUE, **kw))
+    gcfg = rt.make_render_config(aspect_mode=1, **kw)
+    img, gst = g.render(gcfg)
+    t, tri = g.primary_hits(gcfg)
+    assert np.array_equal(tri, ref_tri) and np.array_equal(bits(t), bits(ref_t))
+    assert (tri >= 34).sum() > 100  # the sphere is in view
+    assert gst.rays == st.search_calls and gst.shadow_rays == st.shadow_rays
+    assert np.abs(img - ref).max() <= 1.0 / 255.0
+    # random rays through the deep part of the tree, both culling modes
+    o, d = random_rays(osc, 20000, 3)
+    for cull in (True, False):
+        t_ref, tri_ref = ot.trace_closest(o, d, cull)
+        t2, tri2 = g.trace_closest(o, d, cull)
+        assert np.array_equal(tri2, tri_ref) and np.array_equal(bits(t2), bits(t_ref))
+
+
 def test_render_is_partition_independent(rt, scenes):
     """Rendering the image in interleaved bands (as 2 or 3 ranks would) gives the same pixels as one call."""
     sc = scenes["original"]

@@ -69,6 +69,30 @@ def test_flat_layout(scenes, scene, mb, md):
     assert ht.max_stack <= 128
 
 
+def test_synthetic_tree_equals_oracle_and_reference(orc):
+    """Icosphere-in-Cornell-box scene: level 5 (20,514 triangles) node-for-node against the oracle; level 8
+    (1,310,754 triangles) against the tree shape the reference binary printed (tests/golden/ref_kats.json S8)."""
+    import json
+    from conftest import GOLDEN
+    from raytracer_amd.scene import Scene
+    from raytracer_amd.synthetic import cornell_with_icosphere
+    box = Scene.load_npz(os.path.join(GOLDEN, "scenes", "cornell_original.npz"))
+    s5 = cornell_with_icosphere(box, 5)
+    assert s5.n_triangles == 34 + 20 * 4 ** 5
+    oe = orc.Octree(orc.Scene.from_arrays(s5.pos, None, s5.matid, s5.materials), 16, 10).export()
+    he = HostTree(s5.pos, 16, 10).export()
+    for k in oe:
+        assert same_bits(oe[k], he[k]), k
+    with open(os.path.join(GOLDEN, "ref_kats.json")) as f:
+        ref = json.load(f)["S8"]
+    s8 = cornell_with_icosphere(box, 8)
+    assert s8.n_triangles == 1310754
+    st = HostTree(s8.pos, 16, 10).stats()
+    assert (st["nodes"], st["leaves"], st["max_depth"], st["max_triangles_in_leaf"]) == \
+           (ref["nodes"], ref["leaves"], ref["max_depth"], ref["max_tris_in_leaf"])
+    assert abs(st["avg_leaf_depth"] - ref["avg_leaf_depth"]) < 1e-4 and abs(st["avg_triangles_in_leaf"] - ref["avg_tris_in_leaf"]) < 1e-4
+
+
 def test_empty_and_root_leaf(scenes):
     ht = HostTree(np.zeros((0, 3, 3), np.float32))
     assert ht.n_nodes == 0 and ht.export_flat()[2][1] == 0
