@@ -279,7 +279,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (a->flat.slots.size() > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");
     a->shape = tree_shape(a->host);
     HIP_TRY(a->d_nodes.reserve(a->flat.nodes.size()));
-    HIP_TRY(a->d_slots.reserve(a->flat.slots.size()));
+    HIP_TRY(a->d_slots.reserve(a->flat.slots.size() + 4));  // +4: triangle records are fetched in groups of 4
     HIP_TRY(a->d_tri_geom.reserve(n));
     if (!a->flat.nodes.empty())
         HIP_TRY(hipMemcpy(a->d_nodes.p, a->flat.nodes.data(), a->flat.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
@@ -287,7 +287,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
         HIP_TRY(hipMemcpy(a->d_slots.p, a->flat.slots.data(), a->flat.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
     if (!a->flat.flat_tris.empty()) {
         HIP_TRY(a->d_flat_nodes.reserve(a->flat.flat_nodes.size()));
-        HIP_TRY(a->d_flat_tris.reserve(a->flat.flat_tris.size()));
+        HIP_TRY(a->d_flat_tris.reserve(a->flat.flat_tris.size() + 4));
         HIP_TRY(hipMemcpy(a->d_flat_nodes.p, a->flat.flat_nodes.data(), a->flat.flat_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(a->d_flat_tris.p, a->flat.flat_tris.data(), a->flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
     }

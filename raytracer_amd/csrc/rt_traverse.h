@@ -114,34 +114,59 @@ struct HitState {
     lanemask found;  // any-hit: lanes that have found an occluder (wave-uniform)
 };
 
+// ---- wide scalar loads -------------------------------------------------------------------------------------------
+// Records are fetched in blocks of 16 dwords (s_load_dwordx16) so that a node visit or a group of 4 triangles
+// costs one round trip to the scalar cache instead of one per field.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef u32x16 u32x16_a4 __attribute__((aligned(4)));
+struct Block48 {  // 48 dwords: one node's 8 boxes, or 4 triangle records
+    u32x16 v[3];
+};
+__device__ __forceinline__ u32x16 sload16(cu32_p p) { return *(const RT_CONST u32x16_a4*)p; }
+__device__ __forceinline__ Block48 sload48(cu32_p p) {
+    Block48 b;
+    b.v[0] = sload16(p);
+    b.v[1] = sload16(p + 16);
+    b.v[2] = sload16(p + 32);
+    return b;
+}
+#define RT_W(b, i) ((b).v[(i) >> 4][(i) & 15])
+#define RT_F(b, i) __uint_as_float(RT_W(b, i))
+
+constexpr int kTriChunk = 4;  // triangle records per scalar-load group (arrays are padded by this many records)
+
 // Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.
 template <bool ANY, bool CULL>
 __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, lanemask mine, f3 o, f3 d, float t_limit,
                                            HitState& h) {
-    cfloat_p base = as_const_f(T.slots);
-    for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t slot = begin + k;
-        cfloat_p r = base + (size_t)slot * 12;
-        const f3 a = mk(r[0], r[1], r[2]);
-        const f3 e1 = mk(r[3], r[4], r[5]);
-        const f3 e2 = mk(r[6], r[7], r[8]);
-        float t = RT_INF;
-        const lanemask hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
-        if (hit == 0) continue;
-        if (ANY) {
-            h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
-            mine &= ~h.found;
-            if (mine == 0) break;
-        } else {
-            // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
-            // smaller global slot.
-            const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
-            if (better == 0) continue;
-            const uint32_t tri = __float_as_uint(r[9]);
-            const bool b = lane_of(better);
-            h.t = b ? t : h.t;
-            h.slot = b ? slot : h.slot;
-            h.tri = b ? tri : h.tri;
+    cu32_p base = as_const_u(T.slots);
+    for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
+        const Block48 blk = sload48(base + (size_t)(begin + k0) * 12);
+#pragma unroll
+        for (int j = 0; j < kTriChunk; ++j) {
+            if (k0 + j >= count) break;
+            const uint32_t slot = begin + k0 + j;
+            const f3 a = mk(RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2));
+            const f3 e1 = mk(RT_F(blk, 12 * j + 3), RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5));
+            const f3 e2 = mk(RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8));
+            float t = RT_INF;
+            const lanemask hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
+            if (hit == 0) continue;
+            if (ANY) {
+                h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+                mine &= ~h.found;
+                if (mine == 0) return;
+            } else {
+                // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
+                // smaller global slot.
+                const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
+                if (better == 0) continue;
+                const uint32_t tri = RT_W(blk, 12 * j + 9);
+                const bool b = lane_of(better);
+                h.t = b ? t : h.t;
+                h.slot = b ? slot : h.slot;
+                h.tri = b ? tri : h.tri;
+            }
         }
     }
 }
@@ -155,94 +180,109 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
 // ascending); the loop runs in ascending j, so an equal-t later triangle wins only with a smaller first leaf.
 template <bool ANY, bool CULL>
 __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask alive, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
-    cfloat_p base = as_const_f(T.flat_tris);
+    cu32_p base = as_const_u(T.flat_tris);
     const uint32_t n = T.n_flat_tris;
-    for (uint32_t j = 0; j < n; ++j) {
-        cfloat_p r = base + (size_t)j * 12;
-        const uint32_t lm = __float_as_uint(r[10]);
-        const lanemask need = alive & ballot64((reach & lm) != 0);
-        if (need == 0) continue;
-        const f3 a = mk(r[0], r[1], r[2]);
-        const f3 e1 = mk(r[3], r[4], r[5]);
-        const f3 e2 = mk(r[6], r[7], r[8]);
-        float t = RT_INF;
-        const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
-        if (hit == 0) continue;
-        if (ANY) {
-            h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
-            alive &= ~h.found;
-            if (alive == 0) break;
-        } else {
-            const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);  // garbage on lanes outside `need`
-            const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
-            if (better == 0) continue;
-            const bool b = lane_of(better);
-            h.t = b ? t : h.t;
-            h.slot = b ? first_leaf : h.slot;
-            h.tri = b ? j : h.tri;
+    for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
+        const Block48 blk = sload48(base + (size_t)j0 * 12);
+#pragma unroll
+        for (int jj = 0; jj < kTriChunk; ++jj) {
+            const uint32_t j = j0 + jj;
+            if (j >= n) break;
+            const uint32_t lm = RT_W(blk, 12 * jj + 10);
+            const lanemask need = alive & ballot64((reach & lm) != 0);
+            if (need == 0) continue;
+            const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
+            const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
+            const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
+            float t = RT_INF;
+            const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
+            if (hit == 0) continue;
+            if (ANY) {
+                h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+                alive &= ~h.found;
+                if (alive == 0) return;
+            } else {
+                const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);  // garbage on lanes outside `need`
+                const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
+                if (better == 0) continue;
+                const bool b = lane_of(better);
+                h.t = b ? t : h.t;
+                h.slot = b ? first_leaf : h.slot;
+                h.tri = b ? j : h.tri;
+            }
         }
     }
 }
+
+// The wave-uniform traversal stack: entry i lives in lane (i & 63) of register (i >> 6) of each field.
+// An entry is one octant that some lanes reach: its NodeRec::info pair and the mask of those lanes.
+struct WaveStack {
+    int f0[2] = {0, 0}, f1[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
+    int sp = 0;
+    __device__ __forceinline__ void push(uint32_t info0, uint32_t info1, lanemask m) {
+        if (sp < 64) {
+            f0[0] = write_lane((int)info0, sp, f0[0]);
+            f1[0] = write_lane((int)info1, sp, f1[0]);
+            lo[0] = write_lane((int)(uint32_t)m, sp, lo[0]);
+            hi[0] = write_lane((int)(uint32_t)(m >> 32), sp, hi[0]);
+        } else {
+            f0[1] = write_lane((int)info0, sp - 64, f0[1]);
+            f1[1] = write_lane((int)info1, sp - 64, f1[1]);
+            lo[1] = write_lane((int)(uint32_t)m, sp - 64, lo[1]);
+            hi[1] = write_lane((int)(uint32_t)(m >> 32), sp - 64, hi[1]);
+        }
+        ++sp;
+    }
+    __device__ __forceinline__ void pop(uint32_t& info0, uint32_t& info1, lanemask& m) {
+        --sp;
+        uint32_t mlo, mhi;
+        if (sp < 64) {
+            info0 = (uint32_t)__builtin_amdgcn_readlane(f0[0], sp);
+            info1 = (uint32_t)__builtin_amdgcn_readlane(f1[0], sp);
+            mlo = (uint32_t)__builtin_amdgcn_readlane(lo[0], sp);
+            mhi = (uint32_t)__builtin_amdgcn_readlane(hi[0], sp);
+        } else {
+            info0 = (uint32_t)__builtin_amdgcn_readlane(f0[1], sp - 64);
+            info1 = (uint32_t)__builtin_amdgcn_readlane(f1[1], sp - 64);
+            mlo = (uint32_t)__builtin_amdgcn_readlane(lo[1], sp - 64);
+            mhi = (uint32_t)__builtin_amdgcn_readlane(hi[1], sp - 64);
+        }
+        m = ((lanemask)mhi << 32) | mlo;
+    }
+};
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
 template <bool ANY, bool CULL, bool FLAT>
 __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
-
-    // Register-resident wave-uniform stack: entry i lives in lane (i & 63) of stack register (i >> 6).
-    int s_node0 = 0, s_node1 = 0, s_mlo0 = 0, s_mlo1 = 0, s_mhi0 = 0, s_mhi1 = 0;
-    int sp = 0;
-    uint32_t ni = T.root_info0;
+    WaveStack st;
     uint32_t reach = 0;
-    lanemask mine = all;
     cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);
+    uint32_t i0 = T.root_info0, i1 = T.root_info1;
+    lanemask mine = all;
     for (;;) {
-        cu32_p rec = nodes + (size_t)ni * 64;
-#pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t info1 = rec[48 + c * 2 + 1];
-            if (info1 == 0) continue;  // null or empty octant (octree.cc:195)
-            const uint32_t info0 = rec[48 + c * 2];
-            const float bx0 = __uint_as_float(rec[c * 6 + 0]), by0 = __uint_as_float(rec[c * 6 + 1]), bz0 = __uint_as_float(rec[c * 6 + 2]);
-            const float bx1 = __uint_as_float(rec[c * 6 + 3]), by1 = __uint_as_float(rec[c * 6 + 4]), bz1 = __uint_as_float(rec[c * 6 + 5]);
-            const lanemask pm = mine & ballot64(ray_box(o, inv, bx0, by0, bz0, bx1, by1, bz1));
-            if (pm == 0) continue;
-            if (info1 & kChildInternal) {
-                if (sp < 64) {
-                    s_node0 = write_lane((int)info0, sp, s_node0);
-                    s_mlo0 = write_lane((int)(uint32_t)pm, sp, s_mlo0);
-                    s_mhi0 = write_lane((int)(uint32_t)(pm >> 32), sp, s_mhi0);
-                } else {
-                    s_node1 = write_lane((int)info0, sp - 64, s_node1);
-                    s_mlo1 = write_lane((int)(uint32_t)pm, sp - 64, s_mlo1);
-                    s_mhi1 = write_lane((int)(uint32_t)(pm >> 32), sp - 64, s_mhi1);
-                }
-                ++sp;
-            } else if (FLAT) {
-                reach |= lane_of(pm) ? (1u << info0) : 0u;
-            } else {
-                leaf_tests<ANY, CULL>(T, info0, info1, pm, o, d, t_limit, h);
-                if (ANY) {
-                    mine &= ~h.found;
-                    if (mine == 0) break;
-                }
+        if (i1 & kChildInternal) {
+            // one round trip for the node: the 8 info pairs and the 8 boxes
+            cu32_p rec = nodes + (size_t)i0 * 64;
+            const u32x16 info = sload16(rec + 48);
+            const Block48 box = sload48(rec);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t c1 = info[2 * c + 1];
+                if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
+                const lanemask pm = mine & ballot64(ray_box(o, inv, RT_F(box, 6 * c + 0), RT_F(box, 6 * c + 1), RT_F(box, 6 * c + 2),
+                                                            RT_F(box, 6 * c + 3), RT_F(box, 6 * c + 4), RT_F(box, 6 * c + 5)));
+                if (pm == 0) continue;
+                if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;
+                else st.push(info[2 * c], c1, pm);
             }
+        } else {
+            leaf_tests<ANY, CULL>(T, i0, i1, mine, o, d, t_limit, h);
         }
-        // pop the next internal node that still has a live lane
+        // next entry that still has a live lane
         bool got = false;
-        while (sp > 0) {
-            --sp;
-            uint32_t mlo, mhi;
-            if (sp < 64) {
-                ni = (uint32_t)__builtin_amdgcn_readlane(s_node0, sp);
-                mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo0, sp);
-                mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi0, sp);
-            } else {
-                ni = (uint32_t)__builtin_amdgcn_readlane(s_node1, sp - 64);
-                mlo = (uint32_t)__builtin_amdgcn_readlane(s_mlo1, sp - 64);
-                mhi = (uint32_t)__builtin_amdgcn_readlane(s_mhi1, sp - 64);
-            }
-            mine = ((lanemask)mhi << 32) | mlo;
+        while (st.sp > 0) {
+            st.pop(i0, i1, mine);
             if (ANY) mine &= ~h.found;
             if (mine != 0) {
                 got = true;
@@ -262,10 +302,8 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     h.found = 0;
     const lanemask all = ballot64(valid);
     if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
-    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: every triangle is a candidate (octree.cc:56-63,186-191)
-        leaf_tests<ANY, CULL>(T, T.root_info0, T.root_info1, all, o, d, t_limit, h);
-        return;
-    }
+    // A root that is a leaf makes every triangle a candidate without any box test (octree.cc:56-63,186-191);
+    // traverse_impl handles it as a leaf entry.
     if (T.n_flat_tris) traverse_impl<ANY, CULL, true>(T, all, o, d, t_limit, h);
     else traverse_impl<ANY, CULL, false>(T, all, o, d, t_limit, h);
 }
