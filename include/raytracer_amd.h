@@ -177,7 +177,7 @@ uint32_t rt_rng_u31(uint32_t seed, uint32_t pixel, uint32_t spp_sample, uint32_t
  * The octree exactly as rt_ads_build constructs it before the upload (Octree::Build,
  * src/ADS/Octree/octree.cc:19-171): nodes in the reference's queue (breadth-first) order with their
  * boxes, child links (octant 0..7, -1 = null) and triangle index lists, plus the flattened device
- * layout (256-byte internal-node records, 48-byte leaf-slot records).  For inspection and tests. */
+ * layout (128-byte internal-node records, 48-byte leaf-slot records).  For inspection and tests. */
 typedef struct rt_host_tree rt_host_tree;
 int rt_host_tree_build(const float* positions, uint64_t n_triangles, uint32_t max_triangles_per_bb, uint32_t max_depth,
                        rt_host_tree** out);

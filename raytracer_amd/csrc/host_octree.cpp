@@ -251,9 +251,9 @@ bool build_octree(const float* positions, uint64_t n, uint32_t max_per_bb, uint3
     return true;
 }
 
-void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out) {
+bool flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out, std::string& err) {
     out = FlatOctree();
-    if (t.empty) return;
+    if (t.empty) return true;
     const size_t nn = t.nodes.size();
     std::vector<uint32_t> rec_of(nn, 0), slot_of(nn, 0);
     uint32_t n_rec = 0;
@@ -287,12 +287,25 @@ void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
         deepest_internal = std::max(deepest_internal, n.depth);
         NodeRec& r = out.nodes[rec_of[i]];
         std::memset(&r, 0, sizeof r);
+        bool have_lo[3][2] = {{false, false}, {false, false}, {false, false}};
         for (int o = 0; o < 8; ++o) {
             const int32_t ci = n.child[o];
             if (ci < 0 || t.nodes[ci].tri_count == 0) continue;  // octree.cc:195
             const HostNode& c = t.nodes[ci];
-            r.box[o][0] = c.bmin.x; r.box[o][1] = c.bmin.y; r.box[o][2] = c.bmin.z;
-            r.box[o][3] = c.bmax.x; r.box[o][4] = c.bmax.y; r.box[o][5] = c.bmax.z;
+            const int bit[3] = {(o >> 2) & 1, (o >> 1) & 1, o & 1};
+            const float mn[3] = {c.bmin.x, c.bmin.y, c.bmin.z}, mx[3] = {c.bmax.x, c.bmax.y, c.bmax.z};
+            for (int ax = 0; ax < 3; ++ax) {
+                if (have_lo[ax][bit[ax]]) {
+                    if (std::memcmp(&r.lo[ax][bit[ax]], &mn[ax], 4) != 0 || std::memcmp(&r.hi[ax][bit[ax]], &mx[ax], 4) != 0) {
+                        err = "flatten: octant boxes of node " + std::to_string(i) + " do not share their planes";
+                        return false;
+                    }
+                } else {
+                    r.lo[ax][bit[ax]] = mn[ax];
+                    r.hi[ax][bit[ax]] = mx[ax];
+                    have_lo[ax][bit[ax]] = true;
+                }
+            }
             if (c.leaf) {
                 r.info[o][0] = slot_of[ci];
                 r.info[o][1] = c.tri_count;
@@ -346,10 +359,11 @@ void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
     } else {
         out.root_info[0] = 0;
         out.root_info[1] = kChildInternal;
-        // Depth-first traversal that pushes only internal children: after popping a node at depth d it holds at
-        // most 7 pending siblings per level above plus up to 8 fresh children.
-        out.max_stack = 7 * deepest_internal + 8;
+        // Depth-first traversal that pushes every reached octant (leaves too): after popping a node at depth d the
+        // stack holds at most 7 pending siblings per level above plus up to 8 fresh children.
+        out.max_stack = 8 * deepest_internal + 8;
     }
+    return true;
 }
 
 TreeShape tree_shape(const HostOctree& t) {

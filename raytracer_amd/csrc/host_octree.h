@@ -6,7 +6,7 @@
 // numbered in the reference's queue (breadth-first) order.  It is then flattened into two
 // arrays that the gfx950 kernels read with scalar loads:
 //
-//   NodeRec[ internal node ]  256 B: the boxes of its 8 octants + what each octant is
+//   NodeRec[ internal node ]  128 B: the 12 planes of its 8 octant boxes + what each octant is
 //   LeafTri[ leaf slot ]       48 B: one triangle reference of one leaf, geometry inlined
 //
 // Leaf slots are laid out leaf after leaf in breadth-first leaf order, each leaf's triangles in
@@ -54,14 +54,21 @@ static_assert(sizeof(LeafTri) == 48, "LeafTri must be 48 bytes");
 constexpr uint32_t kChildInternal = 0x80000000u;
 constexpr uint32_t kFlatMaxLeaves = 32, kFlatMaxTris = 1024;
 
-// One internal node.  info[o][1] == 0: octant o is null/empty (skipped before any box test,
-// octree.cc:195); info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0];
-// otherwise a leaf with info[o][1] triangles whose slots start at info[o][0].
-struct alignas(64) NodeRec {
-    float box[8][6];  // min xyz, max xyz of each octant's (inflated) box
+// One internal node.  The boxes of its 8 octants share their planes: octant o = (bx<<2)|(by<<1)|bz has
+// min.x = lo[0][bx], max.x = hi[0][bx], min.y = lo[1][by], ... (octree.cc:93-97 computes every octant's corner from
+// the same per-axis terms, so the two candidates per axis and side are bit-identical across octants; the flattener
+// checks it).  12 plane values replace 48 box floats, and the slab products (min - o) * inv are computed once per
+// plane instead of once per octant -- the same products the reference computes, just not repeated.
+// info[o][1] == 0: octant o is null/empty (skipped before any box test, octree.cc:195);
+// info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0]; otherwise a leaf with info[o][1]
+// triangles whose slots start at info[o][0].
+struct alignas(128) NodeRec {
+    float lo[3][2];  // [axis][bit]: min plane of the octants whose axis bit is 0 / 1
+    float hi[3][2];  // [axis][bit]: max plane
     uint32_t info[8][2];
+    uint32_t pad[4];
 };
-static_assert(sizeof(NodeRec) == 256, "NodeRec must be 256 bytes");
+static_assert(sizeof(NodeRec) == 128, "NodeRec must be 128 bytes");
 
 struct FlatOctree {
     std::vector<NodeRec> nodes;  // internal nodes, breadth-first
@@ -84,7 +91,7 @@ struct TreeShape {
 // triangle lands in at least one octant, octree.cc:124-152) is violated.
 bool build_octree(const float* positions, uint64_t n, uint32_t max_tris_per_bb, uint32_t max_depth, HostOctree& out,
                   std::string& err);
-void flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out);
+bool flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out, std::string& err);
 TreeShape tree_shape(const HostOctree& t);  // octree.cc:226-266
 
 // Exact host versions of the reference's primitives (used by the builder; exported for unit tests).

@@ -182,7 +182,10 @@ int rt_host_tree_build(const float* positions, uint64_t n, uint32_t max_per_bb, 
         delete t;
         return fail(RT_ERR_BUILD, "%s", err.c_str());
     }
-    flatten_octree(t->host, positions, t->flat);
+    if (!flatten_octree(t->host, positions, t->flat, err)) {
+        delete t;
+        return fail(RT_ERR_BUILD, "%s", err.c_str());
+    }
     *out = t;
     return RT_OK;
 }
@@ -273,7 +276,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->positions.assign(positions, positions + n * 9);
     std::string err;
     if (!build_octree(a->positions.data(), n, a->max_per_bb, a->max_depth, a->host, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
-    flatten_octree(a->host, a->positions.data(), a->flat);
+    if (!flatten_octree(a->host, a->positions.data(), a->flat, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
     if (a->flat.max_stack > 128)
         return fail(RT_ERR_UNSUPPORTED, "octree too deep for the register-resident traversal stack (%u > 128 entries)", a->flat.max_stack);
     if (a->flat.slots.size() > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");

@@ -239,7 +239,8 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // The any-hit pass: every shadow / area-light ray of every hit of one level (renderer.cc:217-219, 288-313).
 // One hit per lane; the lane walks its lights x samples in the reference's order, so the 64 rays a wave
 // traverses together at any moment are the same (light, sample) of 64 neighbouring hits.  The result is one
-// visibility bit per (light, sample): vis[(j * n_lights + l) * words + s / 32] bit s % 32 = 1 if not shadowed.
+// visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1 if not shadowed (hit j
+// innermost, so that a wave writes and reads whole 256-byte lines).
 template <bool CULL>
 __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
             traverse<true, CULL>(S.tree, live, P, d_l, dist, h);
             if (!lane_of(h.found)) bits |= 1u << (s & 31);
             if ((s & 31) == 31 || s + 1 == F.spt) {
-                if (live) vis[((size_t)j * S.n_lights + l) * words + (uint32_t)(s >> 5)] = bits;
+                if (live) vis[((size_t)l * words + (uint32_t)(s >> 5)) * n_work + j] = bits;
                 bits = 0;
             }
         }
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
             f3 acc = mk(0, 0, 0);
             uint32_t bits = 0;
             for (int s = 0; s < F.spt; ++s) {
-                if ((s & 31) == 0) bits = vis[((size_t)j * S.n_lights + l) * words + (uint32_t)(s >> 5)];
+                if ((s & 31) == 0) bits = vis[((size_t)l * words + (uint32_t)(s >> 5)) * n_work + j];
                 if (!((bits >> (s & 31)) & 1u)) continue;  // shadowed
                 const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
                 // renderer.cc:220-240
@@ -505,7 +506,8 @@ __global__ void __launch_bounds__(64) k_search(DevOctree T, const float* __restr
         const NodeRec& r = T.nodes[i0];
         for (int c = 0; c < 8; ++c) {
             if (r.info[c][1] == 0) continue;
-            if (!ray_box(o, inv, r.box[c][0], r.box[c][1], r.box[c][2], r.box[c][3], r.box[c][4], r.box[c][5])) continue;
+            const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+            if (!ray_box(o, inv, r.lo[0][bx], r.lo[1][by], r.lo[2][bz], r.hi[0][bx], r.hi[1][by], r.hi[2][bz])) continue;
             if (qt < queue_cap) {
                 q[qt * 2] = r.info[c][0];
                 q[qt * 2 + 1] = r.info[c][1];

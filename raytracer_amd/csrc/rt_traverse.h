@@ -262,16 +262,37 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     lanemask mine = all;
     for (;;) {
         if (i1 & kChildInternal) {
-            // one round trip for the node: the 8 info pairs and the 8 boxes
-            cu32_p rec = nodes + (size_t)i0 * 64;
-            const u32x16 info = sload16(rec + 48);
-            const Block48 box = sload48(rec);
+            // one round trip for the node: 12 planes + 8 info pairs (NodeRec, 32 dwords)
+            cu32_p rec = nodes + (size_t)i0 * 32;
+            const u32x16 pl = sload16(rec);
+            const u32x16 info = sload16(rec + 12);  // dwords 12..27 = info[8][2]
+            // Per axis and per half (octant bit 0 / 1): the slab products of collision_detection.h:77-81,
+            // already ordered by the sign of inv, and folded into the running max / min from -inf / +inf.
+            float tn[3][2], tf[3][2];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float oo = comp(o, ax), ii = comp(inv, ax);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float t0 = (__uint_as_float(pl[ax * 2 + b]) - oo) * ii;
+                    float t1 = (__uint_as_float(pl[6 + ax * 2 + b]) - oo) * ii;
+                    if (ii < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
+                    tn[ax][b] = t0;
+                    tf[ax][b] = t1;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t c1 = info[2 * c + 1];
                 if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
-                const lanemask pm = mine & ballot64(ray_box(o, inv, RT_F(box, 6 * c + 0), RT_F(box, 6 * c + 1), RT_F(box, 6 * c + 2),
-                                                            RT_F(box, 6 * c + 3), RT_F(box, 6 * c + 4), RT_F(box, 6 * c + 5)));
+                const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+                // collision_detection.h:72-85 in its order: x, then y, then z
+                float t_min = std_max(-RT_INF, tn[0][bx]), t_max = std_min(RT_INF, tf[0][bx]);
+                t_min = std_max(t_min, tn[1][by]);
+                t_max = std_min(t_max, tf[1][by]);
+                t_min = std_max(t_min, tn[2][bz]);
+                t_max = std_min(t_max, tf[2][bz]);
+                const lanemask pm = mine & ballot64(t_max >= t_min);
                 if (pm == 0) continue;
                 if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;
                 else st.push(info[2 * c], c1, pm);

@@ -53,7 +53,10 @@ def test_flat_layout(scenes, scene, mb, md):
             if c < 0:
                 assert r["info"][o, 1] == 0
                 continue
-            assert same_bits(r["box"][o, :3], e["bmin"][c]) and same_bits(r["box"][o, 3:], e["bmax"][c])
+            bit = ((o >> 2) & 1, (o >> 1) & 1, o & 1)
+            lo = np.array([r["lo"][ax, bit[ax]] for ax in range(3)], np.float32)
+            hi = np.array([r["hi"][ax, bit[ax]] for ax in range(3)], np.float32)
+            assert same_bits(lo, e["bmin"][c]) and same_bits(hi, e["bmax"][c])
             if e["is_leaf"][c]:
                 assert (int(r["info"][o, 0]), int(r["info"][o, 1])) == (slot_of[c], int(e["tri_count"][c]))
             else:
