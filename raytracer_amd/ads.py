@@ -203,7 +203,8 @@ def make_render_config(cam_pos, cam_up, cam_dir, fov, width, height, spp=1, max_
 class HostTree:
     """The octree exactly as Build constructs it on the host, without touching a GPU (inspection / tests)."""
 
-    NODE_DT = np.dtype([("lo", np.float32, (3, 2)), ("hi", np.float32, (3, 2)), ("info", np.uint32, (8, 2)), ("pad", np.uint32, 4)])
+    NODE_DT = np.dtype([("lo", np.float32, (3, 2)), ("hi", np.float32, (3, 2)), ("nonempty", np.uint32), ("pad", np.uint32, 3),
+                        ("info", np.uint32, (8, 2))])
     SLOT_DT = np.dtype([("a", np.float32, 3), ("e1", np.float32, 3), ("e2", np.float32, 3), ("tri", np.uint32),
                         ("pad", np.uint32, 2)])
 

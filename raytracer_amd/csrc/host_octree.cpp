@@ -313,6 +313,7 @@ bool flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
                 r.info[o][0] = rec_of[ci];
                 r.info[o][1] = kChildInternal;
             }
+            r.nonempty |= 1u << o;
         }
     }
     // small-tree form

@@ -63,10 +63,11 @@ constexpr uint32_t kFlatMaxLeaves = 32, kFlatMaxTris = 1024;
 // info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0]; otherwise a leaf with info[o][1]
 // triangles whose slots start at info[o][0].
 struct alignas(128) NodeRec {
-    float lo[3][2];  // [axis][bit]: min plane of the octants whose axis bit is 0 / 1
-    float hi[3][2];  // [axis][bit]: max plane
+    float lo[3][2];     // [axis][bit]: min plane of the octants whose axis bit is 0 / 1
+    float hi[3][2];     // [axis][bit]: max plane
+    uint32_t nonempty;  // bit o set: octant o exists and lists triangles (info[o][1] != 0)
+    uint32_t pad[3];
     uint32_t info[8][2];
-    uint32_t pad[4];
 };
 static_assert(sizeof(NodeRec) == 128, "NodeRec must be 128 bytes");
 

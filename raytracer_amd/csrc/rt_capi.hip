@@ -81,12 +81,25 @@ struct Level {
 
 constexpr int kMaxTimed = 64;
 
+// Launches KERNEL<cull, lane>(args...) for run-time cull / lane flags.
+#define RT_LAUNCH2(KERNEL, cull, lane, grid, block, stream, ...)                                          \
+    do {                                                                                                  \
+        if (cull) {                                                                                       \
+            if (lane) hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, stream, __VA_ARGS__);       \
+            else hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, stream, __VA_ARGS__);           \
+        } else {                                                                                          \
+            if (lane) hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, stream, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, stream, __VA_ARGS__);          \
+        }                                                                                                 \
+    } while (0)
+
 }  // namespace
 
 struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, use_flat = true;
+    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane
     uint64_t n_tri = 0;
     std::vector<float> positions;
     HostOctree host;
@@ -124,6 +137,18 @@ DevOctree dev_tree(const rt_ads* a) {
     t.flat_tris = a->d_flat_tris.p;
     t.n_flat_tris = a->use_flat ? (uint32_t)a->flat.flat_tris.size() : 0u;
     return t;
+}
+
+// Which traversal a launch uses.  Small trees are always walked by the wave together (their small-tree form bounds the
+// work by the triangle count).  Large trees: camera rays of an 8x8 pixel tile are coherent and stay wave-together;
+// shadow, secondary and caller-supplied rays are walked per lane.
+bool lane_mode(const rt_ads* a, bool coherent_primary) {
+    if (a->traversal == 1) return false;
+    if (a->traversal == 2) return a->flat.max_stack != 0;  // a root-leaf tree has nothing to descend
+    const bool small_tree = a->use_flat && !a->flat.flat_tris.empty();
+    if (small_tree || a->flat.max_stack == 0) return false;
+    if (a->flat.slots.size() < 32768) return false;
+    return !coherent_primary;
 }
 
 int use_device(const rt_ads* a) {
@@ -295,6 +320,10 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
         HIP_TRY(hipMemcpy(a->d_flat_tris.p, a->flat.flat_tris.data(), a->flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
     }
     if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
+    a->traversal = 0;
+    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : 0);
+    if (a->flat.nodes.size() >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 internal nodes");
+    if (a->shape.max_depth > (uint64_t)kLaneMaxLevels) return fail(RT_ERR_UNSUPPORTED, "octree deeper than %d levels", kLaneMaxLevels);
     if (n) {
         std::vector<LeafTri> g(n);
         for (uint64_t i = 0; i < n; ++i) {
@@ -430,8 +459,7 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    if (cull) hipLaunchKernelGGL(k_trace_closest<true>, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
-    else hipLaunchKernelGGL(k_trace_closest<false>, grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
+    RT_LAUNCH2(k_trace_closest, cull != 0, lane_mode(a, false), grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -465,8 +493,7 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    if (cull) hipLaunchKernelGGL(k_trace_any<true>, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out);
-    else hipLaunchKernelGGL(k_trace_any<false>, grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out);
+    RT_LAUNCH2(k_trace_any, cull != 0, lane_mode(a, false), grid, block, stream, dev_tree(a), d_p, d_l, n, d_out);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
@@ -675,8 +702,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const dim3 grid((n + 255) / 256);
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            if (F.cull) hipLaunchKernelGGL(k_closest<true>, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
-            else hipLaunchKernelGGL(k_closest<false>, grid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, cnt);
+            RT_LAUNCH2(k_closest, F.cull != 0, lane_mode(a, L == 0), grid, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+                       lv.work.p, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
                 HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream));
@@ -705,12 +732,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 HIP_TRY(lv.vis.reserve((size_t)n_work * a->n_lights * words));
                 const bool timed_a = n_timed_shadow < kMaxTimed;
                 if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
-                if (F.cull)
-                    hipLaunchKernelGGL(k_shadow<true>, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p,
-                                       lv.vis.p, words, cnt);
-                else
-                    hipLaunchKernelGGL(k_shadow<false>, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p,
-                                       lv.vis.p, words, cnt);
+                RT_LAUNCH2(k_shadow, F.cull != 0, lane_mode(a, false), grid_s, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
+                           lv.work.p, lv.vis.p, words, cnt);
                 HIP_TRY(hipGetLastError());
                 if (timed_a) {
                     HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream));
@@ -807,12 +830,8 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
         d_tri = (int32_t*)(a->d_io.p + npix * 4);
     }
     const dim3 block(256), grid((n0 + 255) / 256);
-    if (F.cull)
-        hipLaunchKernelGGL(k_closest<true>, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p,
-                           lv.out.p, lv.work.p, a->d_counters.p);
-    else
-        hipLaunchKernelGGL(k_closest<false>, grid, block, 0, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p, lv.hit_tri.p,
-                           lv.out.p, lv.work.p, a->d_counters.p);
+    RT_LAUNCH2(k_closest, F.cull != 0, lane_mode(a, true), grid, block, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
+               lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());

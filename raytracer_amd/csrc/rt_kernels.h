@@ -15,8 +15,25 @@
 #include <hip/hip_runtime.h>
 
 #include "rt_traverse.h"
+#include "rt_traverse_lane.h"
 
 namespace rt {
+
+// LANE = false: the wave walks the tree together (rt_traverse.h); LANE = true: every lane walks its own ray
+// (rt_traverse_lane.h), with its stack in the block's LDS.
+template <bool LANE>
+struct LaneStackSlot {
+    LaneStackLds s;
+};
+template <>
+struct LaneStackSlot<false> {
+    uint32_t unused;
+};
+template <bool ANY, bool CULL, bool LANE>
+__device__ __forceinline__ void trace(const DevOctree& T, LaneStackSlot<LANE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    if constexpr (LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
+    else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
+}
 
 struct alignas(16) TriShade {  // per triangle in Build order
     float nx, ny, nz;          // face normal (src/triangle.h:28-32)
@@ -121,7 +138,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // ---- batched queries for caller-supplied rays --------------------------------------------------------------------
 
-template <bool CULL>
+template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
                                                        uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,15 +148,16 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
         o = mk(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
         d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     }
+    __shared__ LaneStackSlot<LANE> lds;
     HitState h;
-    traverse<false, CULL>(T, valid, o, d, 0.0f, h);
+    trace<false, CULL, LANE>(T, lds, valid, o, d, 0.0f, h);
     if (valid) {
         out_t[i] = h.t;
         out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
     }
 }
 
-template <bool CULL>
+template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
                                                    uint64_t n, uint8_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,8 +171,9 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const f3 pl = l - p;
     const float dist = length(pl);
     const f3 d = normalize(pl);
+    __shared__ LaneStackSlot<LANE> lds;
     HitState h;
-    traverse<true, CULL>(T, valid, p, d, dist, h);
+    trace<true, CULL, LANE>(T, lds, valid, p, d, dist, h);
     if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
@@ -185,7 +204,7 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 }
 
 // Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
-template <bool CULL>
+template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
@@ -194,8 +213,9 @@ __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint
     f3 o, d;
     uint32_t pixel, node_id;
     load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
+    __shared__ LaneStackSlot<LANE> lds;
     HitState h;
-    traverse<false, CULL>(S.tree, valid, o, d, 0.0f, h);
+    trace<false, CULL, LANE>(S.tree, lds, valid, o, d, 0.0f, h);
     const bool hit = valid && !(h.t == RT_INF);
     if (valid) {
         hit_t[i] = h.t;
@@ -241,11 +261,12 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // traverses together at any moment are the same (light, sample) of 64 neighbouring hits.  The result is one
 // visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1 if not shadowed (hit j
 // innermost, so that a wave writes and reads whole 256-byte lines).
-template <bool CULL>
+template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
                                                 uint32_t* __restrict__ counters) {
+    __shared__ LaneStackSlot<LANE> lds;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_work = counters[CNT_WORK];
     const bool active = j < n_work;
@@ -279,7 +300,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
             const f3 d_l = normalize(to_l);
             HitState h;
             shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
-            traverse<true, CULL>(S.tree, live, P, d_l, dist, h);
+            trace<true, CULL, LANE>(S.tree, lds, live, P, d_l, dist, h);
             if (!lane_of(h.found)) bits |= 1u << (s & 31);
             if ((s & 31) == 31 || s + 1 == F.spt) {
                 if (live) vis[((size_t)l * words + (uint32_t)(s >> 5)) * n_work + j] = bits;
@@ -324,6 +345,13 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
     const f3 diffuse = mk(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
     const f3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
 
+    // The specular term is (I_l * specular) * pow(base, shininess).  With an all-zero specular colour and a
+    // non-negative shininess the power is finite, so the product is the same zero (or the NaN that I_l already is)
+    // whatever the power's value: a wave none of whose lanes has a specular material skips powf and the two
+    // normalisations that only feed it.
+    const bool spec_is_zero = specular.x == 0.0f && specular.y == 0.0f && specular.z == 0.0f && m.shininess >= 0.0f;
+    const bool wave_needs_pow = ballot64(valid && !spec_is_zero) != 0;
+
     f3 col = mk(0, 0, 0);
     if (F.render_type == 0) {  // renderer.cc:197-200
         const float g = 1.0f - (std_min(t, 1.5f * F.max_distance) / (1.5f * F.max_distance));
@@ -353,19 +381,22 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
                 const f3 d_l = normalize(to_l);
                 const float w = (L.area * std_max(0.0f, dot(n_l, -d_l))) / ((float)F.spt * dist * dist + kEps);
                 const f3 I_l = emission * w;
-                const f3 d_v = normalize(F.cam_pos - P);
                 const f3 I_a = I_l * mk(0, 0, 0);
                 const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));
-                f3 c;
-                if (F.render_type == 2) {  // renderer.cc:249-267
-                    const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
-                    const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
-                    c = ((I_a + I_d) + I_s) + mk(m.emission[0], m.emission[1], m.emission[2]);
-                } else {  // renderer.cc:269-286
-                    const f3 d_h = normalize(d_l + d_v);
-                    const f3 I_s = (I_l * specular) * powf(std_max(0.0f, dot(N, d_h)), m.shininess);
-                    c = (I_a + I_d) + I_s;
+                float pw = 1.0f;  // the power of the specular term; irrelevant on lanes whose specular colour is zero
+                if (wave_needs_pow) {
+                    const f3 d_v = normalize(F.cam_pos - P);
+                    if (F.render_type == 2) {  // renderer.cc:256-263
+                        const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
+                        pw = powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
+                    } else {  // renderer.cc:276-283
+                        const f3 d_h = normalize(d_l + d_v);
+                        pw = powf(std_max(0.0f, dot(N, d_h)), m.shininess);
+                    }
                 }
+                const f3 I_s = (I_l * specular) * pw;
+                f3 c = (I_a + I_d) + I_s;
+                if (F.render_type == 2) c = c + mk(m.emission[0], m.emission[1], m.emission[2]);  // renderer.cc:264-266
                 acc = acc + c;
             }
             final_c = final_c + acc;

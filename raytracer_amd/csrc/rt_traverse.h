@@ -262,10 +262,10 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     lanemask mine = all;
     for (;;) {
         if (i1 & kChildInternal) {
-            // one round trip for the node: 12 planes + 8 info pairs (NodeRec, 32 dwords)
+            // one round trip for the node: 12 planes (+ the non-empty mask) and the 8 info pairs (NodeRec, 32 dwords)
             cu32_p rec = nodes + (size_t)i0 * 32;
             const u32x16 pl = sload16(rec);
-            const u32x16 info = sload16(rec + 12);  // dwords 12..27 = info[8][2]
+            const u32x16 info = sload16(rec + 16);  // dwords 16..31 = info[8][2]
             // Per axis and per half (octant bit 0 / 1): the slab products of collision_detection.h:77-81,
             // already ordered by the sign of inv, and folded into the running max / min from -inf / +inf.
             float tn[3][2], tf[3][2];

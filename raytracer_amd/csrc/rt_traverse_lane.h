@@ -1,0 +1,154 @@
+// rt_traverse_lane.h -- per-lane octree traversal for gfx950 (device only).
+//
+// rt_traverse.h walks the tree once per WAVE: ideal when the 64 rays of a wave reach the same nodes, but its
+// work is the UNION of what the 64 rays reach.  Rays that leave a finely subdivided surface towards 64 different
+// random points of an area light share almost nothing, and the union is then tens of times one ray's work.
+// Here every lane walks its own ray: its own descent, its own leaves, vector loads instead of scalar loads.
+// The wave alternates between two phases ("while-while"): lanes that need a leaf descend (one octant per
+// step: either it is an internal node, whose 8 octants are slab-tested at once, or it is a leaf), then lanes that
+// hold a leaf test one triangle per step.  The work of a wave is the MAXIMUM over its lanes, not the union.
+//
+// Candidate set, arithmetic and tie rule are the same as in rt_traverse.h (see there): every leaf reached through
+// passing slab tests contributes all its triangle references; equal t keeps the smaller global leaf slot.
+//
+// The per-lane stack holds one entry per tree level (record index of an internal node + the 8-bit set of its
+// octants that passed the slab test and are still to be visited), in LDS, laid out [level][thread] so that a lane's
+// bank depends only on its thread index (no conflicts whatever levels the lanes are at).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_traverse.h"
+
+namespace rt {
+
+constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
+constexpr int kLaneBlock = 256;      // threads per block of the kernels that use this traversal
+
+struct LaneStackLds {
+    uint32_t e[kLaneMaxLevels][kLaneBlock];
+};
+
+// Slab tests of the 8 octants of node `rec` for this lane's ray: bit o set iff octant o is non-empty and passes
+// (collision_detection.h:71-86 per octant; the plane products are shared between octants, see NodeRec).
+__device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ nodes, uint32_t rec, f3 o, f3 inv) {
+    const float4* p = reinterpret_cast<const float4*>(nodes + rec);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const float lo[3][2] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}};
+    const float hi[3][2] = {{q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}};
+    const uint32_t nonempty = __float_as_uint(q3.x);
+    float tn[3][2], tf[3][2];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float oo = comp(o, ax), ii = comp(inv, ax);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float t0 = (lo[ax][b] - oo) * ii;
+            float t1 = (hi[ax][b] - oo) * ii;
+            if (ii < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
+            tn[ax][b] = t0;
+            tf[ax][b] = t1;
+        }
+    }
+    uint32_t pass = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+        float t_min = std_max(-RT_INF, tn[0][bx]), t_max = std_min(RT_INF, tf[0][bx]);
+        t_min = std_max(t_min, tn[1][by]);
+        t_max = std_min(t_max, tf[1][by]);
+        t_min = std_max(t_min, tn[2][bz]);
+        t_max = std_min(t_max, tf[2][bz]);
+        pass |= (t_max >= t_min) ? (1u << c) : 0u;
+    }
+    return pass & nonempty;
+}
+
+// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  `stk` is the block's LDS stack.
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& stk, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    h.t = RT_INF;
+    h.slot = 0xffffffffu;
+    h.tri = 0xffffffffu;
+    h.found = 0;
+    if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
+    const uint32_t tid = threadIdx.x;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
+    bool active = valid;
+    bool found = false;
+    uint32_t leaf_slot = 0, leaf_left = 0;
+    uint32_t cur_rec = 0, cur_pending = 0;
+    int sp = 0;
+    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
+        leaf_slot = T.root_info0;
+        leaf_left = active ? T.root_info1 : 0u;
+    } else {
+        cur_rec = T.root_info0;
+        cur_pending = active ? lane_node_pass(T.nodes, cur_rec, o, inv) : 0u;
+    }
+    for (;;) {
+        // ---- phase A: every active lane without a leaf takes descent steps until it has one or is finished
+        while (ballot64(active && leaf_left == 0) != 0) {
+            if (active && leaf_left == 0) {
+                if (cur_pending == 0) {
+                    if (sp == 0) {
+                        active = false;
+                    } else {
+                        --sp;
+                        const uint32_t e = stk.e[sp][tid];
+                        cur_rec = e >> 8;
+                        cur_pending = e & 0xffu;
+                    }
+                } else {
+                    const uint32_t c = (uint32_t)__builtin_ctz(cur_pending);
+                    cur_pending &= cur_pending - 1;
+                    const uint2 info = *reinterpret_cast<const uint2*>(&T.nodes[cur_rec].info[c][0]);
+                    if (info.y & kChildInternal) {
+                        if (cur_pending != 0) {
+                            stk.e[sp][tid] = (cur_rec << 8) | cur_pending;
+                            ++sp;
+                        }
+                        cur_rec = info.x;
+                        cur_pending = lane_node_pass(T.nodes, cur_rec, o, inv);
+                    } else {
+                        leaf_slot = info.x;
+                        leaf_left = info.y;
+                    }
+                }
+            }
+        }
+        if (ballot64(active) == 0) break;
+        // ---- phase B: every lane that holds a leaf tests its triangles, one per step
+        lanemask busy;
+        while ((busy = ballot64(leaf_left != 0)) != 0) {
+            const float4* r = reinterpret_cast<const float4*>(T.slots + (leaf_left != 0 ? leaf_slot : 0u));
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+            float t = RT_INF;
+            const lanemask hit = ray_triangle<CULL>(busy, o, d, a, e1, e2, t);
+            if (hit != 0) {
+                if (ANY) {
+                    const bool f = lane_of(hit & ballot64(t < t_limit));  // renderer.cc:302
+                    found = found || f;
+                    if (f) {  // this ray is decided
+                        active = false;
+                        leaf_left = 1;  // ends the lane's leaf below
+                    }
+                } else {
+                    // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
+                    const bool b = lane_of(hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(leaf_slot < h.slot))));
+                    h.t = b ? t : h.t;
+                    h.slot = b ? leaf_slot : h.slot;
+                    h.tri = b ? __float_as_uint(r2.y) : h.tri;
+                }
+            }
+            if (leaf_left != 0) {
+                ++leaf_slot;
+                --leaf_left;
+            }
+        }
+    }
+    if (ANY) h.found = ballot64(found);
+}
+
+}  // namespace rt

@@ -115,6 +115,37 @@ def test_small_tree_form_equals_general_form(rt, orc, scenes, monkeypatch):
     assert len(verts) > 0
 
 
+@pytest.mark.parametrize("mode", ["wave", "lane"])
+@pytest.mark.parametrize("scene,mb,md", [("sphere", 16, 10), ("sphere", 4, 3), ("original", 8, 2), ("original", 1000, 10)])
+def test_both_traversals(rt, orc, scenes, monkeypatch, mode, scene, mb, md):
+    """The two traversal kernels (the wave walks together / every lane walks its own ray) are forced in turn and must
+    both reproduce the oracle: closest hits, occlusion flags and a rendered frame with shadow and secondary rays."""
+    monkeypatch.setenv("RT_TRAVERSAL", mode)
+    monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    sc = scenes[scene]
+    g = build(rt, sc, mb, md)
+    ot = orc.Octree(sc, mb, md)
+    o, d = random_rays(sc, 30000, 17)
+    for cull in (True, False):
+        t_ref, tri_ref = ot.trace_closest(o, d, cull)
+        t, tri = g.trace_closest(o, d, cull)
+        assert np.array_equal(tri, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+    hit = tri_ref >= 0
+    P = (o[hit] + d[hit] * t_ref[hit, None]).astype(np.float32)
+    rs = np.random.RandomState(5)
+    lt = sc.pos[sc.light_tri[rs.randint(0, sc.n_light, P.shape[0])]]
+    L = (lt[:, 0] * 0.4 + lt[:, 1] * 0.3 + lt[:, 2] * 0.3).astype(np.float32)
+    for cull in (True, False):
+        assert np.array_equal(ot.trace_any(P, L, cull), g.trace_any(P, L, cull))
+    cam = CAMERAS[scene]
+    shading = "smooth" if sc.has_normals else "flat"
+    kw = dict(fov=0.6, width=48, height=40, spt=3, render_type="blinn_phong", shading=shading, **cam)
+    ref, ref_tri, ref_t, st = orc.render(sc, ot, orc.make_cfg(rng_mode=orc.RNG_COUNTER, **kw))
+    img, gst = g.render(rt.make_render_config(**kw))
+    assert gst.rays == st.search_calls
+    assert np.abs(img - ref).max() <= 1.0 / 255.0
+
+
 @pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3)])
 def test_search_candidate_lists(rt, orc, scenes, scene, mb, md):
     sc = scenes[scene]
