@@ -189,6 +189,18 @@ int rt_host_tree_export(const rt_host_tree* t, uint8_t* is_leaf, uint32_t* depth
 int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info2);
 int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out);
 
+/* ---- host-side scene input and image output (no GPU needed) ---------------------------------------------
+ * LoadScene (src/ObjLoader/obj_loader.cc:130-212): Wavefront OBJ/MTL -> triangles in file order with per-vertex
+ * normals and material ids + the material table (18 floats per material as in rt_scene_set_shading).  Quads are
+ * split like the reference's loader does; a face without a valid material is an error. */
+typedef struct rt_scene_data rt_scene_data;
+int rt_scene_load_obj(const char* obj_path, const char* basepath, int triangulate, rt_scene_data** out);
+void rt_scene_data_free(rt_scene_data* s);
+int rt_scene_data_sizes(const rt_scene_data* s, uint64_t* n_triangles, uint32_t* n_materials, int* has_normals);
+int rt_scene_data_export(const rt_scene_data* s, float* positions, float* normals, int32_t* material_ids, float* materials);
+/* Renderer::save_image_to_pmm + write_color (src/Renderer/renderer.cc:381-390, src/color.h:12-15): P3 text. */
+int rt_write_ppm(const char* path, int32_t width, int32_t height, const float* rgb);
+
 const char* rt_last_error(void);
 /* Library / device identification, for logs. */
 const char* rt_version(void);

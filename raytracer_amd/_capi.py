@@ -63,6 +63,7 @@ EXPORTS = [
     "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
     "rt_host_tree_export_flat", "rt_host_tree_stats",
+    "rt_scene_load_obj", "rt_scene_data_free", "rt_scene_data_sizes", "rt_scene_data_export", "rt_write_ppm",
 ]
 
 _lib = None
@@ -106,6 +107,12 @@ def lib():
     L.rt_host_tree_export.argtypes = [vp] * 9
     L.rt_host_tree_export_flat.argtypes = [vp, vp, vp, vp]
     L.rt_host_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
+    L.rt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rt_scene_data_free.argtypes = [vp]
+    L.rt_scene_data_free.restype = None
+    L.rt_scene_data_sizes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.rt_scene_data_export.argtypes = [vp, vp, vp, vp, vp]
+    L.rt_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, vp]
     L.rt_rng_u31.restype = C.c_uint32
     L.rt_rng_u31.argtypes = [C.c_uint32] * 7
     _lib = L

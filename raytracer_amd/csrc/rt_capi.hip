@@ -13,6 +13,7 @@
 #include "../../include/raytracer_amd.h"
 #include "host_octree.h"
 #include "rt_kernels.h"
+#include "scene_io.h"
 
 using namespace rt;
 
@@ -198,6 +199,48 @@ struct rt_host_tree {
 };
 
 extern "C" {
+
+}  // extern "C"
+
+struct rt_scene_data {
+    SceneData d;
+};
+
+extern "C" {
+
+int rt_scene_load_obj(const char* obj_path, const char* basepath, int triangulate, rt_scene_data** out) {
+    if (!obj_path || !out) return fail(RT_ERR_INVALID, "null argument");
+    rt_scene_data* s = new rt_scene_data();
+    std::string err;
+    if (!load_obj(obj_path, basepath ? basepath : "", triangulate != 0, s->d, err)) {
+        delete s;
+        return fail(RT_ERR_INVALID, "%s", err.c_str());
+    }
+    *out = s;
+    return RT_OK;
+}
+void rt_scene_data_free(rt_scene_data* s) { delete s; }
+int rt_scene_data_sizes(const rt_scene_data* s, uint64_t* n_triangles, uint32_t* n_materials, int* has_normals) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    if (n_triangles) *n_triangles = s->d.material_ids.size();
+    if (n_materials) *n_materials = (uint32_t)(s->d.materials.size() / 18);
+    if (has_normals) *has_normals = s->d.has_normals ? 1 : 0;
+    return RT_OK;
+}
+int rt_scene_data_export(const rt_scene_data* s, float* positions, float* normals, int32_t* material_ids, float* materials) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    if (positions && !s->d.positions.empty()) memcpy(positions, s->d.positions.data(), s->d.positions.size() * sizeof(float));
+    if (normals && !s->d.normals.empty()) memcpy(normals, s->d.normals.data(), s->d.normals.size() * sizeof(float));
+    if (material_ids && !s->d.material_ids.empty()) memcpy(material_ids, s->d.material_ids.data(), s->d.material_ids.size() * sizeof(int32_t));
+    if (materials && !s->d.materials.empty()) memcpy(materials, s->d.materials.data(), s->d.materials.size() * sizeof(float));
+    return RT_OK;
+}
+int rt_write_ppm(const char* path, int32_t width, int32_t height, const float* rgb) {
+    if (!path || !rgb || width < 1 || height < 1) return fail(RT_ERR_INVALID, "bad argument");
+    std::string err;
+    if (!write_ppm(path, width, height, rgb, err)) return fail(RT_ERR_INVALID, "%s", err.c_str());
+    return RT_OK;
+}
 
 int rt_host_tree_build(const float* positions, uint64_t n, uint32_t max_per_bb, uint32_t max_depth, rt_host_tree** out) {
     if ((!positions && n) || !out) return fail(RT_ERR_INVALID, "null argument");

@@ -271,6 +271,28 @@ def test_render_is_partition_independent(rt, scenes):
         assert np.array_equal(bits(out), bits(full))
 
 
+def test_renderer_mirror_writes_the_reference_ppm(rt, orc, scenes, tmp_path):
+    """Renderer(config).RenderScene(...) with the reference's config keys: the PPM file it writes is byte-identical to
+    the oracle's for an RNG-free render type (reflections included)."""
+    import hashlib
+    from raytracer_amd import renderer as rr
+    from raytracer_amd.scene import Scene
+    for name, rtype, shading in (("original", "distance", "flat"), ("sphere", "diffusion", "smooth")):
+        sc = scenes[name]
+        out = tmp_path / f"{name}.ppm"
+        cfg = {"max_depth": 10, "samples_per_triangle": 1, "render_type": rtype, "max_distance": CAMERAS[name]["max_distance"],
+               "shading_type": shading, "cull_backfaces": True, "background_color": [0.01, 0.01, 0.01],
+               "acceleratied_data_structure": {"name": "octree_gpu", "max_triangles_per_BB": 16, "max_depth": 10},
+               "output": {"filename": str(out)}}
+        cam = rr.Camera({"pos": CAMERAS[name]["cam_pos"], "up": CAMERAS[name]["cam_up"], "dir": CAMERAS[name]["cam_dir"], "fov": 0.6,
+                         "width": 100, "height": 100, "samples_per_pixel": 1})
+        scene = Scene(sc.pos, sc.norm if sc.has_normals else None, sc.matid, sc.materials, has_normals=sc.has_normals)
+        rr.Renderer(cfg).RenderScene(scene, cam, log=None)
+        ref, _, _, _ = orc.render(sc, orc.Octree(sc, 16, 10),
+                                  orc.make_cfg(fov=0.6, width=100, height=100, render_type=rtype, shading=shading, **CAMERAS[name]))
+        assert hashlib.md5(out.read_bytes()).hexdigest() == orc.ppm_md5(ref)
+
+
 def test_errors(rt, scenes):
     g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
     with pytest.raises(RuntimeError, match="rt_ads_build"):
