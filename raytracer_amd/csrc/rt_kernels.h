@@ -136,6 +136,26 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
     return base + (uint32_t)__builtin_popcountll(below);
 }
 
+// The same for a whole 256-thread block with ONE atomic per block: a single counter word sustains only some tens of
+// atomics per microsecond, and a 1080p level has 32k waves.  Every thread of the block must call it (once per kernel).
+__device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want) {
+    __shared__ uint32_t s_count[4];
+    __shared__ uint32_t s_base;
+    const uint64_t m = ballot64(want);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_count[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_base;
+    for (uint32_t w = 0; w < wave; ++w) at += s_count[w];
+    const uint64_t below = m & ((1ull << lane) - 1ull);
+    return at + (uint32_t)__builtin_popcountll(below);
+}
+
 // ---- batched queries for caller-supplied rays --------------------------------------------------------------------
 
 template <bool CULL, bool LANE>
@@ -228,7 +248,7 @@ __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint
             out[i] = r;
         }
     }
-    const uint32_t slot = wave_append(&counters[CNT_WORK], hit);
+    const uint32_t slot = block_append(&counters[CNT_WORK], hit);
     if (hit) work[slot] = i;
 }
 
