@@ -217,37 +217,34 @@ __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask alive, u
 // The wave-uniform traversal stack: entry i lives in lane (i & 63) of register (i >> 6) of each field.
 // An entry is one octant that some lanes reach: its NodeRec::info pair and the mask of those lanes.
 struct WaveStack {
-    int f0[2] = {0, 0}, f1[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
+    // named registers on purpose: an array indexed by (sp >= 64) would be placed in scratch memory
+    int f0a = 0, f0b = 0, f1a = 0, f1b = 0, loa = 0, lob = 0, hia = 0, hib = 0;
     int sp = 0;
     __device__ __forceinline__ void push(uint32_t info0, uint32_t info1, lanemask m) {
-        if (sp < 64) {
-            f0[0] = write_lane((int)info0, sp, f0[0]);
-            f1[0] = write_lane((int)info1, sp, f1[0]);
-            lo[0] = write_lane((int)(uint32_t)m, sp, lo[0]);
-            hi[0] = write_lane((int)(uint32_t)(m >> 32), sp, hi[0]);
-        } else {
-            f0[1] = write_lane((int)info0, sp - 64, f0[1]);
-            f1[1] = write_lane((int)info1, sp - 64, f1[1]);
-            lo[1] = write_lane((int)(uint32_t)m, sp - 64, lo[1]);
-            hi[1] = write_lane((int)(uint32_t)(m >> 32), sp - 64, hi[1]);
-        }
+        // branch-free: at most one of the two compares holds for a lane
+        const int lane = (int)__lane_id();
+        const bool ha = lane == sp, hb = lane + 64 == sp;
+        f0a = ha ? (int)info0 : f0a;
+        f1a = ha ? (int)info1 : f1a;
+        loa = ha ? (int)(uint32_t)m : loa;
+        hia = ha ? (int)(uint32_t)(m >> 32) : hia;
+        f0b = hb ? (int)info0 : f0b;
+        f1b = hb ? (int)info1 : f1b;
+        lob = hb ? (int)(uint32_t)m : lob;
+        hib = hb ? (int)(uint32_t)(m >> 32) : hib;
         ++sp;
     }
     __device__ __forceinline__ void pop(uint32_t& info0, uint32_t& info1, lanemask& m) {
         --sp;
-        uint32_t mlo, mhi;
-        if (sp < 64) {
-            info0 = (uint32_t)__builtin_amdgcn_readlane(f0[0], sp);
-            info1 = (uint32_t)__builtin_amdgcn_readlane(f1[0], sp);
-            mlo = (uint32_t)__builtin_amdgcn_readlane(lo[0], sp);
-            mhi = (uint32_t)__builtin_amdgcn_readlane(hi[0], sp);
-        } else {
-            info0 = (uint32_t)__builtin_amdgcn_readlane(f0[1], sp - 64);
-            info1 = (uint32_t)__builtin_amdgcn_readlane(f1[1], sp - 64);
-            mlo = (uint32_t)__builtin_amdgcn_readlane(lo[1], sp - 64);
-            mhi = (uint32_t)__builtin_amdgcn_readlane(hi[1], sp - 64);
-        }
-        m = ((lanemask)mhi << 32) | mlo;
+        const int l = sp & 63;
+        const bool first = sp < 64;
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane(f0a, l), b0 = (uint32_t)__builtin_amdgcn_readlane(f0b, l);
+        const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane(f1a, l), b1 = (uint32_t)__builtin_amdgcn_readlane(f1b, l);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane(loa, l), b2 = (uint32_t)__builtin_amdgcn_readlane(lob, l);
+        const uint32_t a3 = (uint32_t)__builtin_amdgcn_readlane(hia, l), b3 = (uint32_t)__builtin_amdgcn_readlane(hib, l);
+        info0 = first ? a0 : b0;
+        info1 = first ? a1 : b1;
+        m = ((lanemask)(first ? a3 : b3) << 32) | (first ? a2 : b2);
     }
 };
 
