@@ -53,6 +53,10 @@ enum rt_shading_type { RT_SHADING_FLAT = 0, RT_SHADING_SMOOTH = 1 };
  * (renderer.cc:93); RT_ASPECT_TRUE uses the real ratio. */
 enum rt_aspect_mode { RT_ASPECT_COMPAT = 0, RT_ASPECT_TRUE = 1 };
 
+/* Where Octree::Build runs.  Both builders produce the same tree, bit for bit; RT_BUILDER_AUTO builds scenes of
+ * fewer than 16384 triangles on the host and larger ones on the device. */
+enum rt_builder { RT_BUILDER_AUTO = 0, RT_BUILDER_HOST = 1, RT_BUILDER_DEVICE = 2 };
+
 /* Maps a config name to rt_ads_kind; returns RT_ERR_INVALID for unknown names
  * (renderer.cc:374-376: "Invalid data structure"). */
 int rt_ads_kind_from_name(const char* name, int* out_kind);
@@ -64,6 +68,7 @@ typedef struct rt_ads_config {
     int32_t device;                 /* HIP device ordinal */
     uint32_t max_triangles_per_bb;  /* "max_triangles_per_BB" */
     uint32_t max_depth;             /* "max_depth" */
+    uint32_t builder;               /* rt_builder; optional key "builder": "auto" | "host" | "device" */
 } rt_ads_config;
 
 /* Ads::Ads + Octree::Octree (src/ADS/ads.h:18, src/ADS/Octree/octree.h:17). */
@@ -74,10 +79,16 @@ void rt_ads_destroy(rt_ads* ads);
 /* Ads::Build / Octree::Build (src/ADS/ads.h:21, src/ADS/Octree/octree.cc:19-171).
  * positions: n_triangles x 3 vertices x 3 floats, host memory, triangle order = the order of the
  * reference's Scene::GetTriangles().  The data is copied; the caller may free it afterwards.
- * Builds the octree on the host with the reference's exact splitting rule, flattens it in
- * breadth-first order and uploads it.  n_triangles == 0 is accepted (octree.cc:24-27); queries
- * then report no candidates. */
+ * Builds the octree with the reference's exact splitting rule -- on the host (then flattened in breadth-first
+ * order and uploaded) or directly on the device, one pass per depth (rt_builder) -- into the same resident
+ * layout.  n_triangles == 0 is accepted (octree.cc:24-27); queries then report no candidates. */
 int rt_ads_build(rt_ads* ads, const float* positions, uint64_t n_triangles);
+
+/* Copies the resident tree back to the host: internal-node records (128 bytes each) and leaf slots (48 bytes
+ * each) in the layout of rt_host_tree_export_flat, for inspection and for comparing the two builders.  Any
+ * pointer may be NULL; the counts are always reported.  No reference counterpart beyond Octree::PrintStats. */
+int rt_ads_export_tree(const rt_ads* ads, void* node_records, void* leaf_slots, uint32_t* root_info2, uint64_t* n_records,
+                       uint64_t* n_slots, uint32_t* max_stack, int* built_on_device);
 
 /* Octree::PrintStats / calculate_stats, structural part (src/ADS/Octree/octree.cc:209-266). */
 typedef struct rt_tree_stats {

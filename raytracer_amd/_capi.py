@@ -18,7 +18,10 @@ RT_ASPECT_COMPAT, RT_ASPECT_TRUE = 0, 1
 
 class AdsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_triangles_per_bb", C.c_uint32),
-                ("max_depth", C.c_uint32)]
+                ("max_depth", C.c_uint32), ("builder", C.c_uint32)]
+
+
+BUILDERS = {"auto": 0, "host": 1, "device": 2}
 
 
 class TreeStats(C.Structure):
@@ -58,7 +61,7 @@ class RenderStats(C.Structure):
 
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
-    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_tree_stats",
+    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_stats",
     "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_search", "rt_ads_trace_closest", "rt_ads_trace_any",
     "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
@@ -91,6 +94,7 @@ def lib():
     L.rt_ads_destroy.argtypes = [vp]
     L.rt_ads_destroy.restype = None
     L.rt_ads_build.argtypes = [vp, vp, C.c_uint64]
+    L.rt_ads_export_tree.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
     L.rt_ads_reset_query_stats.argtypes = [vp]

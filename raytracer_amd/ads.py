@@ -51,14 +51,19 @@ class GpuOctree(Ads):
     """The MI355X backend behind the reference's Ads interface.
 
     config: the "acceleratied_data_structure" object; reads "max_triangles_per_BB" and "max_depth"
-    (octree.cc:268-275; a missing key raises KeyError like json::at).  triangles for Build: array of
-    shape (n, 3, 3) (vertex positions in the scene's triangle order)."""
+    (octree.cc:268-275; a missing key raises KeyError like json::at) and the optional "builder"
+    ("auto" | "host" | "device": where Octree::Build runs).  triangles for Build: array of shape (n, 3, 3)
+    (vertex positions in the scene's triangle order)."""
 
     def __init__(self, config, device=0):
         super().__init__(config)
         self.max_triangles_per_BB_ = int(config["max_triangles_per_BB"])
         self.max_depth_ = int(config["max_depth"])
-        cfg = _capi.AdsConfig(C.sizeof(_capi.AdsConfig), int(device), self.max_triangles_per_BB_, self.max_depth_)
+        builder = str(config.get("builder", "auto"))
+        if builder not in _capi.BUILDERS:
+            raise RuntimeError("Invalid builder")
+        cfg = _capi.AdsConfig(C.sizeof(_capi.AdsConfig), int(device), self.max_triangles_per_BB_, self.max_depth_,
+                              _capi.BUILDERS[builder])
         h = C.c_void_p()
         _capi.check(_capi.lib().rt_ads_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -163,6 +168,16 @@ class GpuOctree(Ads):
         tri = np.zeros(n, np.int32)
         _capi.check(_capi.lib().rt_render_primary_hits(self._h, C.byref(cfg), _p(t), _p(tri), _capi.RT_MEM_HOST, None))
         return t, tri
+
+    def export_tree(self):
+        """The resident tree copied back: (node records, leaf slots, root_info, max_stack, built_on_device)."""
+        nr, ns, ms, dev = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_int()
+        root = (C.c_uint32 * 2)()
+        _capi.check(_capi.lib().rt_ads_export_tree(self._h, None, None, root, C.byref(nr), C.byref(ns), C.byref(ms), C.byref(dev)))
+        nodes = np.zeros(nr.value, HostTree.NODE_DT)
+        slots = np.zeros(ns.value, HostTree.SLOT_DT)
+        _capi.check(_capi.lib().rt_ads_export_tree(self._h, _p(nodes), _p(slots), root, None, None, None, None))
+        return nodes, slots, (int(root[0]), int(root[1])), int(ms.value), bool(dev.value)
 
     def tree_stats(self):
         st = _capi.TreeStats()

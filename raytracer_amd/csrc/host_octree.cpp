@@ -1,5 +1,6 @@
 // host_octree.cpp -- see host_octree.h.
 #include "host_octree.h"
+#include "rt_sat.h"
 
 #include <algorithm>
 #include <atomic>
@@ -10,57 +11,9 @@
 
 namespace rt {
 
-f3 face_normal(const f3 v[3]) {
-    // src/triangle.h:28-32: cross(b - a, c - b), normalised with the guarded division.
-    return normalize(cross(v[1] - v[0], v[2] - v[1]));
-}
+f3 face_normal(const f3 v[3]) { return face_normal3(v[0], v[1], v[2]); }
 
-namespace {
-
-// std::min({a,b,c}) / std::max({a,b,c}) return the first smallest / largest element.
-inline float min3(float a, float b, float c) {
-    float m = a;
-    if (b < m) m = b;
-    if (c < m) m = c;
-    return m;
-}
-inline float max3(float a, float b, float c) {
-    float m = a;
-    if (m < b) m = b;
-    if (m < c) m = c;
-    return m;
-}
-
-inline bool axis_separates(f3 axis, f3 v0, f3 v1, f3 v2, f3 half) {
-    const float p0 = dot(v0, axis), p1 = dot(v1, axis), p2 = dot(v2, axis);
-    const float r = half.x * fabsf(axis.x) + half.y * fabsf(axis.y) + half.z * fabsf(axis.z);
-    return min3(p0, p1, p2) > r || max3(p0, p1, p2) < -r;
-}
-
-}  // namespace
-
-bool tri_box_overlap(const f3 v[3], f3 normal, f3 bmin, f3 bmax) {
-    const f3 center = (bmin + bmax) * 0.5f;
-    const f3 half = (bmax - bmin) * 0.5f;
-    const f3 v0 = v[0] - center, v1 = v[1] - center, v2 = v[2] - center;
-    const f3 e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
-    // 1. box axes
-    for (int i = 0; i < 3; ++i) {
-        const float mn = min3(comp(v0, i), comp(v1, i), comp(v2, i));
-        const float mx = max3(comp(v0, i), comp(v1, i), comp(v2, i));
-        if (mn > comp(half, i) || mx < -comp(half, i)) return false;
-    }
-    // 2. triangle plane, with the stored (normalised) face normal
-    const float p0 = dot(v0, normal);
-    const float r = half.x * fabsf(normal.x) + half.y * fabsf(normal.y) + half.z * fabsf(normal.z);
-    if (fabsf(p0) > r) return false;
-    // 3. nine edge cross products, in the reference's order
-    const f3 axes[9] = {mk(0, -e0.z, e0.y), mk(0, -e1.z, e1.y), mk(0, -e2.z, e2.y), mk(e0.z, 0, -e0.x), mk(e1.z, 0, -e1.x),
-                        mk(e2.z, 0, -e2.x), mk(-e0.y, e0.x, 0), mk(-e1.y, e1.x, 0), mk(-e2.y, e2.x, 0)};
-    for (const f3& a : axes)
-        if (axis_separates(a, v0, v1, v2, half)) return false;
-    return true;
-}
+bool tri_box_overlap(const f3 v[3], f3 normal, f3 bmin, f3 bmax) { return sat_tri_box(v[0], v[1], v[2], normal, bmin, bmax); }
 
 namespace {
 
@@ -120,7 +73,7 @@ bool build_octree(const float* positions, uint64_t n, uint32_t max_per_bb, uint3
         tris[i].n = face_normal(tris[i].v);
     }
 
-    const float aabb_eps = 1e-6f;  // octree.cc:30
+    const float aabb_eps = kAabbEps;
     f3 mn = tris[0].v[0], mx = tris[0].v[0];  // octree.cc:33-44
     for (const TriGeom& t : tris)
         for (const f3& p : t.v) {
@@ -166,16 +119,8 @@ bool build_octree(const float* positions, uint64_t n, uint32_t max_per_bb, uint3
         work.resize(todo.size());
         for (size_t k = 0; k < todo.size(); ++k) {  // octree.cc:81-97
             const HostNode& cur = out.nodes[todo[k]];
-            const f3 half = div_guard(vabs(cur.bmax - cur.bmin), 2.0f);
-            const f3 min_eps = vabs(cur.bmin) * aabb_eps;
-            const f3 max_eps = vabs(cur.bmax) * aabb_eps;
-            for (unsigned o = 0; o < 8; ++o) {
-                const f3 omin = mk(cur.bmin.x + (half.x * (float)((o & 4) >> 2)), cur.bmin.y + (half.y * (float)((o & 2) >> 1)),
-                                   cur.bmin.z + (half.z * (float)(o & 1)));
-                const f3 omax = omin + half;
-                work[k].cmin[o] = omin - min_eps;
-                work[k].cmax[o] = omax + max_eps;
-            }
+            const OctantFrame fr = octant_frame(cur.bmin, cur.bmax);
+            for (unsigned o = 0; o < 8; ++o) octant_box(fr, o, work[k].cmin[o], work[k].cmax[o]);
         }
         parallel_for(todo.size() * 8, workers, [&](size_t task) {  // octree.cc:100-105
             const size_t k = task >> 3;

@@ -12,6 +12,7 @@
 
 #include "../../include/raytracer_amd.h"
 #include "host_octree.h"
+#include "rt_build.h"
 #include "rt_kernels.h"
 #include "scene_io.h"
 
@@ -52,6 +53,25 @@ struct DevBuf {  // grow-only device buffer
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // like reserve, but the first `keep` elements survive a reallocation (capacity at least doubles)
+    hipError_t grow_keep(size_t n, size_t keep) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = std::max<size_t>({n, 2 * cap, 64});
+        T* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpy(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(q);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -81,6 +101,7 @@ struct Level {
 };
 
 constexpr int kMaxTimed = 64;
+constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 
 // Launches KERNEL<cull, lane>(args...) for run-time cull / lane flags.
 #define RT_LAUNCH2(KERNEL, cull, lane, grid, block, stream, ...)                                          \
@@ -101,10 +122,16 @@ struct rt_ads {
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, use_flat = true;
     int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane
+    int builder = 0;    // rt_builder requested at creation
+    bool device_built = false;
     uint64_t n_tri = 0;
     std::vector<float> positions;
-    HostOctree host;
-    FlatOctree flat;
+    // summary of the resident tree (the arrays themselves live in d_nodes / d_slots / d_flat_*)
+    bool empty = true;
+    uint32_t root_info[2] = {0, 0};
+    uint32_t max_stack = 0;
+    uint64_t n_rec = 0, n_slots = 0, n_tree_nodes = 0, n_flat_tris = 0;
+    double build_seconds = 0.0;
     TreeShape shape;
     DevBuf<NodeRec> d_nodes;
     DevBuf<LeafTri> d_slots, d_tri_geom, d_flat_tris;
@@ -130,13 +157,13 @@ DevOctree dev_tree(const rt_ads* a) {
     DevOctree t;
     t.nodes = a->d_nodes.p;
     t.slots = a->d_slots.p;
-    t.root_info0 = a->flat.root_info[0];
-    t.root_info1 = a->host.empty ? 0u : a->flat.root_info[1];
-    t.n_nodes = (uint32_t)a->flat.nodes.size();
-    t.n_slots = (uint32_t)a->flat.slots.size();
+    t.root_info0 = a->root_info[0];
+    t.root_info1 = a->empty ? 0u : a->root_info[1];
+    t.n_nodes = (uint32_t)a->n_rec;
+    t.n_slots = (uint32_t)a->n_slots;
     t.flat_nodes = a->d_flat_nodes.p;
     t.flat_tris = a->d_flat_tris.p;
-    t.n_flat_tris = a->use_flat ? (uint32_t)a->flat.flat_tris.size() : 0u;
+    t.n_flat_tris = a->use_flat ? (uint32_t)a->n_flat_tris : 0u;
     return t;
 }
 
@@ -145,10 +172,10 @@ DevOctree dev_tree(const rt_ads* a) {
 // shadow, secondary and caller-supplied rays are walked per lane.
 bool lane_mode(const rt_ads* a, bool coherent_primary) {
     if (a->traversal == 1) return false;
-    if (a->traversal == 2) return a->flat.max_stack != 0;  // a root-leaf tree has nothing to descend
-    const bool small_tree = a->use_flat && !a->flat.flat_tris.empty();
-    if (small_tree || a->flat.max_stack == 0) return false;
-    if (a->flat.slots.size() < 32768) return false;
+    if (a->traversal == 2) return a->max_stack != 0;  // a root-leaf tree has nothing to descend
+    const bool small_tree = a->use_flat && a->n_flat_tris != 0;
+    if (small_tree || a->max_stack == 0) return false;
+    if (a->n_slots < 32768) return false;
     return !coherent_primary;
 }
 
@@ -318,6 +345,11 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
     a->device = cfg->device;
     a->max_per_bb = cfg->max_triangles_per_bb;
     a->max_depth = cfg->max_depth;
+    if (cfg->builder > RT_BUILDER_DEVICE) {
+        delete a;
+        return fail(RT_ERR_INVALID, "unknown builder %u", cfg->builder);
+    }
+    a->builder = (int)cfg->builder;
     *out = a;
     return RT_OK;
 }
@@ -334,39 +366,49 @@ void rt_ads_destroy(rt_ads* a) {
     delete a;
 }
 
-int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
-    if (!a || (!positions && n)) return fail(RT_ERR_INVALID, "null argument");
-    if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 triangles");
-    if (int rc = use_device(a)) return rc;
-    a->built = false;
-    a->shading_set = false;
-    a->n_tri = n;
-    a->positions.assign(positions, positions + n * 9);
-    std::string err;
-    if (!build_octree(a->positions.data(), n, a->max_per_bb, a->max_depth, a->host, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
-    if (!flatten_octree(a->host, a->positions.data(), a->flat, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
-    if (a->flat.max_stack > 128)
-        return fail(RT_ERR_UNSUPPORTED, "octree too deep for the register-resident traversal stack (%u > 128 entries)", a->flat.max_stack);
-    if (a->flat.slots.size() > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");
-    a->shape = tree_shape(a->host);
-    HIP_TRY(a->d_nodes.reserve(a->flat.nodes.size()));
-    HIP_TRY(a->d_slots.reserve(a->flat.slots.size() + 4));  // +4: triangle records are fetched in groups of 4
-    HIP_TRY(a->d_tri_geom.reserve(n));
-    if (!a->flat.nodes.empty())
-        HIP_TRY(hipMemcpy(a->d_nodes.p, a->flat.nodes.data(), a->flat.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-    if (!a->flat.slots.empty())
-        HIP_TRY(hipMemcpy(a->d_slots.p, a->flat.slots.data(), a->flat.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-    if (!a->flat.flat_tris.empty()) {
-        HIP_TRY(a->d_flat_nodes.reserve(a->flat.flat_nodes.size()));
-        HIP_TRY(a->d_flat_tris.reserve(a->flat.flat_tris.size() + 4));
-        HIP_TRY(hipMemcpy(a->d_flat_nodes.p, a->flat.flat_nodes.data(), a->flat.flat_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(a->d_flat_tris.p, a->flat.flat_tris.data(), a->flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-    }
-    if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
-    a->traversal = 0;
-    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : 0);
-    if (a->flat.nodes.size() >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 internal nodes");
+}  // extern "C"
+
+namespace {
+
+int check_tree_limits(const rt_ads* a) {
+    if (a->max_stack > 128)
+        return fail(RT_ERR_UNSUPPORTED, "octree too deep for the register-resident traversal stack (%u > 128 entries)", a->max_stack);
+    if (a->n_slots > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");
+    if (a->n_rec >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 internal nodes");
     if (a->shape.max_depth > (uint64_t)kLaneMaxLevels) return fail(RT_ERR_UNSUPPORTED, "octree deeper than %d levels", kLaneMaxLevels);
+    return RT_OK;
+}
+
+// Octree::Build on the host (host_octree.cpp), flattened and uploaded.
+int host_build(rt_ads* a) {
+    const uint64_t n = a->n_tri;
+    HostOctree host;
+    FlatOctree flat;
+    std::string err;
+    if (!build_octree(a->positions.data(), n, a->max_per_bb, a->max_depth, host, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
+    if (!flatten_octree(host, a->positions.data(), flat, err)) return fail(RT_ERR_BUILD, "%s", err.c_str());
+    a->empty = host.empty;
+    a->root_info[0] = flat.root_info[0];
+    a->root_info[1] = flat.root_info[1];
+    a->max_stack = flat.max_stack;
+    a->n_rec = flat.nodes.size();
+    a->n_slots = flat.slots.size();
+    a->n_tree_nodes = host.nodes.size();
+    a->n_flat_tris = flat.flat_tris.size();
+    a->build_seconds = host.build_seconds;
+    a->shape = tree_shape(host);
+    if (int rc = check_tree_limits(a)) return rc;
+    HIP_TRY(a->d_nodes.reserve(flat.nodes.size()));
+    HIP_TRY(a->d_slots.reserve(flat.slots.size() + 4));  // +4: triangle records are fetched in groups of 4
+    HIP_TRY(a->d_tri_geom.reserve(n));
+    if (!flat.nodes.empty()) HIP_TRY(hipMemcpy(a->d_nodes.p, flat.nodes.data(), flat.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    if (!flat.slots.empty()) HIP_TRY(hipMemcpy(a->d_slots.p, flat.slots.data(), flat.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    if (!flat.flat_tris.empty()) {
+        HIP_TRY(a->d_flat_nodes.reserve(flat.flat_nodes.size()));
+        HIP_TRY(a->d_flat_tris.reserve(flat.flat_tris.size() + 4));
+        HIP_TRY(hipMemcpy(a->d_flat_nodes.p, flat.flat_nodes.data(), flat.flat_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(a->d_flat_tris.p, flat.flat_tris.data(), flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    }
     if (n) {
         std::vector<LeafTri> g(n);
         for (uint64_t i = 0; i < n; ++i) {
@@ -380,8 +422,239 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
         }
         HIP_TRY(hipMemcpy(a->d_tri_geom.p, g.data(), n * sizeof(LeafTri), hipMemcpyHostToDevice));
     }
+    return RT_OK;
+}
+
+// 8-channel exclusive scan of n elements (rt_build.h); out receives n + 1 elements.
+template <bool MASK>
+int scan8(const void* in, uint32_t n, DevBuf<uint32_t>& bsum, uint32_t* out) {
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    HIP_TRY(bsum.reserve(((size_t)nb + 1) * 8));
+    if (nb) hipLaunchKernelGGL((k_scan_reduce<MASK>), dim3(nb), dim3(kScanThreads), 0, 0, in, n, bsum.p);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kScanThreads), 0, 0, bsum.p, nb);
+    hipLaunchKernelGGL((k_scan_write<MASK>), dim3(std::max(nb, 1u)), dim3(kScanThreads), 0, 0, in, n, bsum.p, nb, out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Octree::Build on the device (rt_build.h): one pass per depth, the tree is written directly in its resident layout.
+int device_build(rt_ads* a) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)a->n_tri;
+    a->empty = n == 0;
+    a->root_info[0] = a->root_info[1] = 0;
+    a->max_stack = 0;
+    a->n_rec = a->n_slots = a->n_tree_nodes = a->n_flat_tris = 0;
+    a->shape = TreeShape();
+    a->build_seconds = 0.0;
+    if (n == 0) return RT_OK;  // octree.cc:24-27
+
+    // root box on the host (octree.cc:33-48): a min/max sweep over the caller's array
+    const float* pos = a->positions.data();
+    f3 mn = mk(pos[0], pos[1], pos[2]), mx = mn;
+    for (uint64_t i = 0; i < (uint64_t)n * 3; ++i) {
+        const float* p = pos + i * 3;
+        mn.x = p[0] < mn.x ? p[0] : mn.x;
+        mn.y = p[1] < mn.y ? p[1] : mn.y;
+        mn.z = p[2] < mn.z ? p[2] : mn.z;
+        mx.x = p[0] > mx.x ? p[0] : mx.x;
+        mx.y = p[1] > mx.y ? p[1] : mx.y;
+        mx.z = p[2] > mx.z ? p[2] : mx.z;
+    }
+    const f3 rmin = mn - vabs(mn * mk(kAabbEps, kAabbEps, kAabbEps));
+    const f3 rmax = mx + vabs(mx * mk(kAabbEps, kAabbEps, kAabbEps));
+
+    DevBuf<float> d_pos;
+    DevBuf<TriBuild> d_tb;
+    DevBuf<BuildNode> d_bn[2];
+    DevBuf<uint32_t> d_list[2], d_owner[2], d_S, d_V, d_P, d_cinfo, d_bsum, d_flags;
+    DevBuf<uint8_t> d_mask;
+    uint32_t* h_tot = nullptr;
+    auto cleanup = [&] {
+        d_pos.release(); d_tb.release(); d_bn[0].release(); d_bn[1].release(); d_list[0].release(); d_list[1].release();
+        d_owner[0].release(); d_owner[1].release(); d_S.release(); d_V.release(); d_P.release(); d_cinfo.release();
+        d_bsum.release(); d_flags.release(); d_mask.release();
+        if (h_tot) (void)hipHostFree(h_tot);
+    };
+#define BUILD_TRY(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            cleanup();                                                                                         \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                                      \
+    } while (0)
+#define BUILD_RC(expr)         \
+    do {                       \
+        if (int rc_ = (expr)) { \
+            cleanup();         \
+            return rc_;        \
+        }                      \
+    } while (0)
+
+    const dim3 blk(256);
+    auto grid = [](uint32_t count) { return dim3((count + 255) / 256); };
+    BUILD_TRY(hipHostMalloc((void**)&h_tot, 16 * sizeof(uint32_t)));
+    BUILD_TRY(d_pos.reserve((size_t)n * 9));
+    BUILD_TRY(d_tb.reserve(n));
+    BUILD_TRY(a->d_tri_geom.reserve(n));
+    BUILD_TRY(d_flags.reserve(2));  // [0] = triangles of subdivided nodes that reached no octant, [1] = largest leaf
+    BUILD_TRY(hipMemcpy(d_pos.p, pos, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    BUILD_TRY(hipMemsetAsync(d_flags.p, 0, 2 * sizeof(uint32_t), 0));
+    hipLaunchKernelGGL(k_build_prep, grid(n), blk, 0, 0, d_pos.p, n, d_tb.p, a->d_tri_geom.p);
+    // depth 0: the root and the identity list
+    BUILD_TRY(d_bn[0].reserve(1));
+    BUILD_TRY(d_list[0].reserve(n));
+    BUILD_TRY(d_owner[0].reserve(n));
+    {
+        BuildNode root{};
+        root.bmin[0] = rmin.x; root.bmin[1] = rmin.y; root.bmin[2] = rmin.z;
+        root.bmax[0] = rmax.x; root.bmax[1] = rmax.y; root.bmax[2] = rmax.z;
+        root.begin = 0;
+        root.count = n;
+        root.parent = kNoParent;
+        BUILD_TRY(hipMemcpy(d_bn[0].p, &root, sizeof root, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_build_iota, grid(n), blk, 0, 0, d_list[0].p, n);
+    BUILD_TRY(hipMemsetAsync(d_owner[0].p, 0, (size_t)n * sizeof(uint32_t), 0));
+    // first guesses for the outputs; both grow (keeping their contents) when a depth needs more
+    BUILD_TRY(a->d_nodes.reserve(std::max<size_t>(1024, n / 8)));
+    BUILD_TRY(a->d_slots.reserve((size_t)n * 3 + 4));
+
+    uint32_t n_nodes = 1, n_list = n;
+    uint64_t rec_base = 0, slot_base = 0;
+    uint64_t total_nodes = 0, leaves = 0, total_depth = 0, total_tris = 0, max_leaf_depth = 0;
+    int deepest_internal = -1;
+    bool root_internal = false;
+    int cur = 0;
+    for (uint32_t depth = 0;; ++depth) {
+        const int at_max = depth == a->max_depth ? 1 : 0;
+        BUILD_TRY(d_mask.reserve(n_list));
+        BUILD_TRY(d_S.reserve(((size_t)n_list + 1) * 8));
+        BUILD_TRY(d_V.reserve((size_t)n_nodes * 8));
+        BUILD_TRY(d_P.reserve(((size_t)n_nodes + 1) * 8));
+        BUILD_TRY(d_cinfo.reserve((size_t)n_nodes * 16));
+        hipLaunchKernelGGL(k_build_masks, grid(n_list), blk, 0, 0, d_bn[cur].p, d_list[cur].p, d_owner[cur].p, n_list, d_tb.p,
+                           a->max_per_bb, at_max, d_mask.p, d_flags.p);
+        BUILD_RC(scan8<true>(d_mask.p, n_list, d_bsum, d_S.p));
+        hipLaunchKernelGGL(k_build_decide, grid(n_nodes), blk, 0, 0, d_bn[cur].p, n_nodes, d_S.p, a->max_per_bb, at_max, (int)depth,
+                           d_V.p, d_flags.p + 1);
+        BUILD_RC(scan8<false>(d_V.p, n_nodes, d_bsum, d_P.p));
+        BUILD_TRY(hipMemcpyAsync(h_tot, d_P.p + (size_t)n_nodes * 8, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0));
+        BUILD_TRY(hipMemcpyAsync(h_tot + 8, d_flags.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0));
+        BUILD_TRY(hipStreamSynchronize(0));
+        const uint32_t n_int = h_tot[CH_INTERNAL], n_slot = h_tot[CH_SLOTS], n_child = h_tot[CH_CHILDREN], n_child_list = h_tot[CH_CHILD_LIST];
+        if (h_tot[8] != 0) {
+            cleanup();
+            return fail(RT_ERR_BUILD, "octree build: %u triangles of subdivided nodes at depth %u were assigned to no octant", h_tot[8], depth);
+        }
+        if (rec_base + n_int >= (1u << 24)) {
+            cleanup();
+            return fail(RT_ERR_UNSUPPORTED, "more than 2^24 internal nodes");
+        }
+        if (slot_base + n_slot > 0x7fffffffull || (uint64_t)n_child_list > 0x7fffffffull) {
+            cleanup();
+            return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 leaf triangle references");
+        }
+        const uint32_t n_leaf_nodes = n_nodes - n_int;
+        total_nodes += n_nodes;
+        if (depth > 0) {
+            leaves += n_leaf_nodes;
+            total_depth += (uint64_t)depth * n_leaf_nodes;
+            total_tris += n_slot;
+            if (n_leaf_nodes) max_leaf_depth = depth;
+        } else {
+            root_internal = n_int != 0;
+        }
+        if (n_int) deepest_internal = (int)depth;
+        BUILD_TRY(a->d_nodes.grow_keep(rec_base + n_int, rec_base));
+        BUILD_TRY(a->d_slots.grow_keep(slot_base + n_slot + 4, slot_base));
+        const int nxt = cur ^ 1;
+        BUILD_TRY(d_bn[nxt].reserve(n_child));
+        BUILD_TRY(d_list[nxt].reserve(n_child_list));
+        BUILD_TRY(d_owner[nxt].reserve(n_child_list));
+        hipLaunchKernelGGL(k_build_emit, grid(n_nodes), blk, 0, 0, d_bn[cur].p, n_nodes, d_S.p, d_P.p, (uint32_t)rec_base, (uint32_t)slot_base,
+                           a->d_nodes.p, d_bn[nxt].p, d_cinfo.p);
+        hipLaunchKernelGGL(k_build_scatter, grid(n_list), blk, 0, 0, d_bn[cur].p, d_list[cur].p, d_owner[cur].p, d_mask.p, d_S.p, d_P.p,
+                           d_cinfo.p, n_list, (uint32_t)slot_base, a->d_tri_geom.p, a->d_slots.p, d_list[nxt].p, d_owner[nxt].p);
+        BUILD_TRY(hipGetLastError());
+        rec_base += n_int;
+        slot_base += n_slot;
+        if (n_child == 0) break;
+        n_nodes = n_child;
+        n_list = n_child_list;
+        cur = nxt;
+    }
+    BUILD_TRY(hipMemcpy(h_tot, d_flags.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));  // also waits for the last pass
+    const uint32_t max_leaf = h_tot[1];
+    cleanup();
+#undef BUILD_TRY
+#undef BUILD_RC
+
+    a->n_rec = rec_base;
+    a->n_slots = slot_base;
+    a->n_tree_nodes = total_nodes;
+    a->root_info[0] = 0;
+    if (root_internal) {
+        a->root_info[1] = kChildInternal;
+        a->max_stack = 8u * (uint32_t)deepest_internal + 8u;  // see flatten_octree
+    } else {
+        a->root_info[1] = n;  // root leaf: every triangle is a candidate (octree.cc:56-63, 186-191)
+        a->max_stack = 0;
+    }
+    TreeShape& s = a->shape;  // octree.cc:226-266
+    s.nodes = total_nodes;
+    s.internal = rec_base;
+    s.leaves = leaves;
+    s.leaf_refs = slot_base;
+    s.max_depth = max_leaf_depth;
+    s.max_tris_in_leaf = max_leaf;
+    s.avg_leaf_depth = (float)(long long)total_depth / (float)leaves;
+    s.avg_tris_in_leaf = (float)(long long)total_tris / (float)leaves;
+    a->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return check_tree_limits(a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
+    if (!a || (!positions && n)) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 triangles");
+    if (int rc = use_device(a)) return rc;
+    a->built = false;
+    a->shading_set = false;
+    a->n_tri = n;
+    a->positions.assign(positions, positions + n * 9);
+    int builder = a->builder;
+    if (const char* e = getenv("RT_BUILDER")) builder = !strcmp(e, "host") ? RT_BUILDER_HOST : (!strcmp(e, "device") ? RT_BUILDER_DEVICE : builder);
+    // small scenes build in microseconds on the host and get the small-tree form; large ones are built on the device
+    a->device_built = builder == RT_BUILDER_DEVICE || (builder == RT_BUILDER_AUTO && n >= kDeviceBuildMinTriangles);
+    if (int rc = a->device_built ? device_build(a) : host_build(a)) return rc;
+    if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
+    a->traversal = 0;
+    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : 0);
     if (!a->h_counters) HIP_TRY(hipHostMalloc((void**)&a->h_counters, 64 * CNT_WORDS * sizeof(uint32_t)));
     a->built = true;
+    return RT_OK;
+}
+
+int rt_ads_export_tree(const rt_ads* a, void* node_records, void* leaf_slots, uint32_t* root_info2, uint64_t* n_records,
+                       uint64_t* n_slots, uint32_t* max_stack, int* built_on_device) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (int rc = use_device(a)) return rc;
+    if (n_records) *n_records = a->n_rec;
+    if (n_slots) *n_slots = a->n_slots;
+    if (max_stack) *max_stack = a->max_stack;
+    if (built_on_device) *built_on_device = a->device_built ? 1 : 0;
+    if (root_info2) {
+        root_info2[0] = a->root_info[0];
+        root_info2[1] = a->empty ? 0u : a->root_info[1];
+    }
+    if (node_records && a->n_rec) HIP_TRY(hipMemcpy(node_records, a->d_nodes.p, a->n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    if (leaf_slots && a->n_slots) HIP_TRY(hipMemcpy(leaf_slots, a->d_slots.p, a->n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -397,8 +670,8 @@ int rt_ads_tree_stats(const rt_ads* a, rt_tree_stats* out) {
     out->avg_triangles_in_leaf = a->shape.avg_tris_in_leaf;
     out->leaf_refs = a->shape.leaf_refs;
     out->internal_nodes = a->shape.internal;
-    out->build_seconds = a->host.build_seconds;
-    out->device_bytes = a->flat.nodes.size() * sizeof(NodeRec) + a->flat.slots.size() * sizeof(LeafTri) + a->n_tri * sizeof(LeafTri);
+    out->build_seconds = a->build_seconds;
+    out->device_bytes = a->n_rec * sizeof(NodeRec) + a->n_slots * sizeof(LeafTri) + a->n_tri * sizeof(LeafTri);
     return RT_OK;
 }
 
@@ -422,7 +695,7 @@ int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offset
     if (n == 0) return RT_OK;
     if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
     // A ray can enqueue every node once; chunk the batch so that the queues fit a bounded workspace.
-    const uint64_t queue_cap = std::max<uint64_t>(a->host.nodes.size(), 1);
+    const uint64_t queue_cap = std::max<uint64_t>(a->n_tree_nodes, 1);
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / (queue_cap * 8)));
     DevBuf<float> d_rays;
     DevBuf<uint32_t> d_queue, d_out;

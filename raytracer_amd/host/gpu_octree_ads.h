@@ -38,6 +38,12 @@ class GpuOctree : public Ads {
         c.max_triangles_per_bb = config.at("max_triangles_per_BB");
         c.max_depth = config.at("max_depth");
         c.device = config.contains("device") ? static_cast<int>(config.at("device")) : 0;
+        if (config.contains("builder")) {  // optional: where Build runs; both builders give the same tree
+            const std::string b = config.at("builder");
+            if (b == "host") c.builder = RT_BUILDER_HOST;
+            else if (b == "device") c.builder = RT_BUILDER_DEVICE;
+            else if (b != "auto") throw std::runtime_error("Invalid builder");
+        }
         check(rt_ads_create(&c, &handle_));
     }
     ~GpuOctree() override { rt_ads_destroy(handle_); }

@@ -255,6 +255,45 @@ def test_synthetic_icosphere_scene(rt, orc, levels, w, h, spt):
         assert np.array_equal(tri2, tri_ref) and np.array_equal(bits(t2), bits(t_ref))
 
 
+def synthetic_scene(levels):
+    import os
+    from conftest import GOLDEN
+    from raytracer_amd.scene import Scene
+    from raytracer_amd.synthetic import cornell_with_icosphere
+    return cornell_with_icosphere(Scene.load_npz(os.path.join(GOLDEN, "scenes", "cornell_original.npz")), levels)
+
+
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("original", 8, 2), ("original", 1000, 10), ("original", 4, 0),
+                                         ("sphere", 16, 10), ("sphere", 4, 3), ("sphere", 2, 12), ("ico5", 16, 10),
+                                         ("ico6", 8, 7), ("ico8", 16, 10)])
+def test_device_builder_equals_host_builder(rt, scenes, scene, mb, md):
+    """Octree::Build run on the device gives the resident tree of the host builder bit for bit: internal-node
+    records (octant planes, links, counts), leaf slots in the reference's candidate order, root link, stack bound and
+    the PrintStats figures."""
+    from raytracer_amd.ads import HostTree
+    pos = synthetic_scene(int(scene[3:])).pos if scene.startswith("ico") else scenes[scene].pos
+    g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md, "builder": "device"})
+    g.Build(pos)
+    nodes, slots, root, max_stack, on_device = g.export_tree()
+    assert on_device
+    h = HostTree(pos, mb, md)
+    h_nodes, h_slots, h_root = h.export_flat()
+    assert root == tuple(int(x) for x in h_root) and max_stack == h.max_stack
+    assert nodes.shape == h_nodes.shape and slots.shape == h_slots.shape
+    assert nodes.tobytes() == h_nodes.tobytes()
+    assert slots.tobytes() == h_slots.tobytes()
+    st, hst = g.tree_stats(), h.stats()
+    for key in ("max_depth", "nodes", "leaves", "max_triangles_in_leaf", "leaf_refs", "internal_nodes"):
+        assert st[key] == hst[key], key
+    for key in ("avg_leaf_depth", "avg_triangles_in_leaf"):
+        assert st[key] == hst[key] or (np.isnan(st[key]) and np.isnan(hst[key])), key
+    # and the host-built resident tree is what rt_host_tree_export_flat shows
+    g2 = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md, "builder": "host"})
+    g2.Build(pos)
+    n2, s2, r2, m2, d2 = g2.export_tree()
+    assert not d2 and n2.tobytes() == h_nodes.tobytes() and s2.tobytes() == h_slots.tobytes() and r2 == root and m2 == max_stack
+
+
 def test_render_is_partition_independent(rt, scenes):
     """Rendering the image in interleaved bands (as 2 or 3 ranks would) gives the same pixels as one call."""
     sc = scenes["original"]
