@@ -1048,8 +1048,12 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 HIP_TRY(lv.vis.reserve((size_t)n_work * a->n_lights * words));
                 const bool timed_a = n_timed_shadow < kMaxTimed;
                 if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
-                RT_LAUNCH2(k_shadow, F.cull != 0, lane_mode(a, false), grid_s, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
-                           lv.work.p, lv.vis.p, words, cnt);
+                // lanes per hit in the any-hit pass: the light-sample count rounded up to a power of two, at most 64
+                uint32_t gshift = 0;
+                while ((1u << gshift) < (uint32_t)c->samples_per_triangle && gshift < 6) ++gshift;
+                const dim3 grid_a((uint32_t)((((uint64_t)n_work << gshift) + 255) / 256));
+                RT_LAUNCH2(k_shadow, F.cull != 0, lane_mode(a, false), grid_a, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
+                           lv.work.p, lv.vis.p, words, gshift, cnt);
                 HIP_TRY(hipGetLastError());
                 if (timed_a) {
                     HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream));

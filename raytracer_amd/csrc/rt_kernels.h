@@ -96,7 +96,8 @@ struct FrameParams {
     int32_t spp;
 };
 
-enum { CNT_WORK = 0, CNT_NEXT = 1, CNT_SHADOW_LO = 2, CNT_SHADOW_HI = 3, CNT_WORDS = 4 };
+// Per-level counters.  Each sits in its own 128-byte line: atomics on one line are served one after the other.
+enum { CNT_WORK = 0, CNT_NEXT = 32, CNT_SHADOW_LO = 64, CNT_SHADOW_HI = 65, CNT_WORDS = 96 };
 
 // ---- helpers ---------------------------------------------------------------------------------------------------
 
@@ -138,16 +139,26 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // The same for a whole 256-thread block with ONE atomic per block: a single counter word sustains only some tens of
 // atomics per microsecond, and a 1080p level has 32k waves.  Every thread of the block must call it (once per kernel).
-__device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want) {
+// `weight` is summed over the block into the 64-bit counter at `sum64` (also one atomic per block).
+__device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, uint32_t weight, uint32_t* sum64) {
     __shared__ uint32_t s_count[4];
+    __shared__ uint32_t s_weight[4];
     __shared__ uint32_t s_base;
     const uint64_t m = ballot64(want);
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (lane == 0) s_count[wave] = (uint32_t)__builtin_popcountll(m);
+    uint32_t w = weight;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+    if (lane == 0) {
+        s_count[wave] = (uint32_t)__builtin_popcountll(m);
+        s_weight[wave] = w;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
         s_base = total ? atomicAdd(counter, total) : 0u;
+        const uint32_t wsum = s_weight[0] + s_weight[1] + s_weight[2] + s_weight[3];
+        if (wsum) atomicAdd((unsigned long long*)sum64, (unsigned long long)wsum);
     }
     __syncthreads();
     uint32_t at = s_base;
@@ -248,7 +259,15 @@ __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint
             out[i] = r;
         }
     }
-    const uint32_t slot = block_append(&counters[CNT_WORK], hit);
+    // The shadow / area-light rays this hit will cost (renderer.cc:206-219): samples_per_triangle for every light
+    // before the one the hit triangle itself is (the light loop returns there), all lights otherwise.
+    uint32_t shadow_rays = 0;
+    if (hit && F.render_type >= 2 && F.spt > 0) {
+        const int32_t light_eq = S.tri_shade[h.tri].light_eq;
+        const uint32_t lights = (light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights;
+        shadow_rays = lights * (uint32_t)F.spt;
+    }
+    const uint32_t slot = block_append(&counters[CNT_WORK], hit, shadow_rays, &counters[CNT_SHADOW_LO]);
     if (hit) work[slot] = i;
 }
 
@@ -277,17 +296,21 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 }
 
 // The any-hit pass: every shadow / area-light ray of every hit of one level (renderer.cc:217-219, 288-313).
-// One hit per lane; the lane walks its lights x samples in the reference's order, so the 64 rays a wave
-// traverses together at any moment are the same (light, sample) of 64 neighbouring hits.  The result is one
-// visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1 if not shadowed (hit j
-// innermost, so that a wave writes and reads whole 256-byte lines).
+// A hit owns 2^gshift neighbouring lanes (the samples-per-light count rounded up to a power of two, at most 64):
+// lane `sub` of the group traces sample sub, sub + 2^gshift, ... of each light in turn, so the 64 rays a wave
+// traverses together leave from 64 >> gshift surface points towards one light, and a launch has enough waves to
+// fill the chip even for a few thousand hits.  The result is one visibility bit per (light, sample):
+// vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1 if not shadowed (hit j innermost); the bits of a word come
+// from one ballot, so no two lanes ever write the same word.
 template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
-                                                uint32_t* __restrict__ counters) {
+                                                uint32_t gshift, uint32_t* __restrict__ counters) {
     __shared__ LaneStackSlot<LANE> lds;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t group = 1u << gshift;
+    const uint32_t j = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> gshift);
+    const uint32_t sub = threadIdx.x & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
     const bool active = j < n_work;
     uint32_t i = 0;
@@ -305,32 +328,32 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
     }
     const f3 P = o + (d * t);  // renderer.cc:146
     const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
-    uint32_t shadow_rays = 0;  // wave-uniform
-    bool live = valid;          // still inside render_local_ilumination's light loop
+    // the lanes whose ballot bits form one visibility word: a whole group, or 32 lanes of a 64-lane group
+    const uint32_t word_lanes = group < 32u ? group : 32u;
+    const uint32_t word_first_lane = (uint32_t)__lane_id() & ~(word_lanes - 1u);
+    const uint32_t word_mask = word_lanes == 32u ? 0xffffffffu : ((1u << word_lanes) - 1u);
+    const bool writer = (sub & (word_lanes - 1u)) == 0u;
+    bool live = valid;  // still inside render_local_ilumination's light loop
     for (uint32_t l = 0; l < S.n_lights; ++l) {
         if (light_eq == (int32_t)l) live = false;  // renderer.cc:212-214: the hit triangle is this light
         if (ballot64(live) == 0) break;
         const LightDev L = S.lights[l];
-        uint32_t bits = 0;
-        for (int s = 0; s < F.spt; ++s) {
-            const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
+        for (uint32_t s0 = 0; s0 < (uint32_t)F.spt; s0 += group) {
+            const uint32_t smp = s0 + sub;
+            const bool on = live && smp < (uint32_t)F.spt;
+            const f3 p_l = light_sample(L, pre, l, smp);
             // renderer.cc:289-290
             const f3 to_l = p_l - P;
             const float dist = length(to_l);
             const f3 d_l = normalize(to_l);
             HitState h;
-            shadow_rays += (uint32_t)__builtin_popcountll(ballot64(live));
-            trace<true, CULL, LANE>(S.tree, lds, live, P, d_l, dist, h);
-            if (!lane_of(h.found)) bits |= 1u << (s & 31);
-            if ((s & 31) == 31 || s + 1 == F.spt) {
-                if (live) vis[((size_t)l * words + (uint32_t)(s >> 5)) * n_work + j] = bits;
-                bits = 0;
-            }
+            const lanemask on_mask = ballot64(on);
+            trace<true, CULL, LANE>(S.tree, lds, on, P, d_l, dist, h);
+            const lanemask unshadowed = on_mask & ~h.found;
+            const uint32_t word = (smp >> 5);
+            if (live && writer && word < words)
+                vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
         }
-    }
-    if (__lane_id() == 0 && shadow_rays) {
-        const uint32_t old = atomicAdd(&counters[CNT_SHADOW_LO], shadow_rays);
-        if (old + shadow_rays < old) atomicAdd(&counters[CNT_SHADOW_HI], 1u);
     }
 }
 
