@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libraytracer_amd.so")
+# RT_LIB_PATH selects another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(HERE, "lib", "libraytracer_amd.so")
 
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 RT_ADS_NONE, RT_ADS_OCTREE, RT_ADS_OCTREE_PARAMETRIC, RT_ADS_OCTREE_GPU = 0, 1, 2, 3

@@ -12,6 +12,10 @@
 //   k_search_count / k_search_fill: Ads::Search restated (breadth-first candidate lists)
 #pragma once
 
+#ifndef RT_XCD_CHUNK
+#define RT_XCD_CHUNK 16
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include "rt_traverse.h"
@@ -124,6 +128,23 @@ __device__ __forceinline__ f3 primary_dir(const FrameParams& F, int x, int y, ui
     return dir;
 }
 
+// Hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2.  This maps the hardware
+// block index to a logical one such that an XCD receives runs of RT_XCD_CHUNK consecutive logical blocks: neighbouring
+// rays (which walk the same part of the tree) then share an L2 instead of spreading over all eight.  Short runs keep
+// the eight XCDs equally loaded when cost varies over the image.
+__device__ __forceinline__ uint32_t xcd_block() {
+#if RT_XCD_CHUNK > 1
+    constexpr uint32_t kGroup = 8u * RT_XCD_CHUNK;
+    const uint32_t b = blockIdx.x;
+    const uint32_t g = b / kGroup;
+    if ((g + 1u) * kGroup > gridDim.x) return b;  // the incomplete last group keeps the hardware order
+    const uint32_t r = b - g * kGroup;
+    return g * kGroup + (r & 7u) * RT_XCD_CHUNK + (r >> 3);
+#else
+    return blockIdx.x;
+#endif
+}
+
 // Appends one item per lane with `want` set to a global list; returns the lane's slot.
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
     const uint64_t m = ballot64(want);
@@ -172,7 +193,7 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
 template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
                                                        uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (valid) {
@@ -191,7 +212,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
 template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
                                                    uint64_t n, uint8_t* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
     if (valid) {
@@ -239,7 +260,7 @@ template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = xcd_block() * blockDim.x + threadIdx.x;
     bool valid;
     f3 o, d;
     uint32_t pixel, node_id;
@@ -309,7 +330,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
                                                 uint32_t gshift, uint32_t* __restrict__ counters) {
     __shared__ LaneStackSlot<LANE> lds;
     const uint32_t group = 1u << gshift;
-    const uint32_t j = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> gshift);
+    const uint32_t j = (uint32_t)(((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> gshift);
     const uint32_t sub = threadIdx.x & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
     const bool active = j < n_work;

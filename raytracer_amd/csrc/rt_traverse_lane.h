@@ -24,6 +24,11 @@ namespace rt {
 
 constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
 constexpr int kLaneBlock = 256;      // threads per block of the kernels that use this traversal
+#ifndef RT_LANE_PHASE_RATIO
+#define RT_LANE_PHASE_RATIO 2
+#endif
+// a phase is left early when the lanes it still serves are fewer than 1/kLanePhaseRatio of the lanes waiting for the other phase
+constexpr int kLanePhaseRatio = RT_LANE_PHASE_RATIO;
 
 struct LaneStackLds {
     uint32_t e[kLaneMaxLevels][kLaneBlock];
@@ -87,8 +92,13 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
         cur_pending = active ? lane_node_pass(T.nodes, cur_rec, o, inv) : 0u;
     }
     for (;;) {
-        // ---- phase A: every active lane without a leaf takes descent steps until it has one or is finished
-        while (ballot64(active && leaf_left == 0) != 0) {
+        // ---- phase A: active lanes without a leaf take descent steps.  The phase ends when they all hold a leaf
+        // (or are finished), or earlier once few of them are still searching: those resume in the next round.
+        for (;;) {
+            const lanemask searching = ballot64(active && leaf_left == 0);
+            if (searching == 0) break;
+            const lanemask holding = ballot64(leaf_left != 0);
+            if (__builtin_popcountll(searching) * kLanePhaseRatio < __builtin_popcountll(holding)) break;
             if (active && leaf_left == 0) {
                 if (cur_pending == 0) {
                     if (sp == 0) {
@@ -118,11 +128,21 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
         }
         if (ballot64(active) == 0) break;
-        // ---- phase B: every lane that holds a leaf tests its triangles, one per step
-        lanemask busy;
-        while ((busy = ballot64(leaf_left != 0)) != 0) {
-            const float4* r = reinterpret_cast<const float4*>(T.slots + (leaf_left != 0 ? leaf_slot : 0u));
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+        // ---- phase B: lanes that hold a leaf test its triangles, one per step, the next record already in flight
+        // (the slot array is padded, so reading one record past a leaf's end is harmless).  The phase ends when all
+        // leaves are done, or earlier once few lanes are still testing while others wait for a new leaf.
+        const float4* r = reinterpret_cast<const float4*>(T.slots + (leaf_left != 0 ? leaf_slot : 0u));
+        float4 n0 = r[0], n1 = r[1], n2 = r[2];
+        for (;;) {
+            const lanemask busy = ballot64(leaf_left != 0);
+            if (busy == 0) break;
+            const lanemask idle = ballot64(active && leaf_left == 0);
+            if (__builtin_popcountll(busy) * kLanePhaseRatio < __builtin_popcountll(idle)) break;
+            const float4 r0 = n0, r1 = n1, r2 = n2;
+            const float4* q = reinterpret_cast<const float4*>(T.slots + (leaf_left > 1 ? leaf_slot + 1u : 0u));
+            n0 = q[0];
+            n1 = q[1];
+            n2 = q[2];
             const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
             float t = RT_INF;
             const lanemask hit = ray_triangle<CULL>(busy, o, d, a, e1, e2, t);
