@@ -80,8 +80,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the RCCL path (gather, reductions, barriers) with a single rank: a check of the
+    # multi-rank code on a one-GPU box.
+    force_dist = world == 1 and os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
@@ -113,7 +121,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +146,7 @@ def main():
         closest_rays += st.primary_rays + st.secondary_rays
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -204,16 +212,22 @@ def main():
             roof["other_kernels"]["k_closest"]["achieved_TFLOPs"] = closest_rays * flops_closest / max(closest_ms * 1e-3, 1e-12) / 1e12
         # HBM bytes per k_shadow launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
         # same command; they cannot be collected from inside the run, so the committed summary is quoted.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if pmc_files and world == 1:
+            with open(pmc_files[-1]) as f:
                 pmc = json.load(f)
-            if pmc.get("workload") == args.workload and world == 1:
+            if pmc.get("workload") == args.workload:
                 roof["traffic"] = pmc["k_shadow_bytes_per_launch_corrected"]["mean_over_launches"]
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                          "separate runs, reads doubled per the gfx950 rule; bytes per launch)")
+                # per hit: work index + t + triangle index read (12 B), one visibility word per light and 32 samples written
+                n_lights = max(len(scene.light_triangles()), 1)
+                hits = (shadow_rays / max(shadow_launches, 1)) / (wl["spt"] * n_lights)
+                roof["algorithmic_bytes_per_launch"] = hits * (12.0 + 4.0 * n_lights * ((wl["spt"] + 31) // 32))
         out["roofline"] = roof
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,7 +37,7 @@ def alloc_frame(height, width, world, device):
 
 
 class BandGather:
-    """Pre-allocated gather of the bands to rank 0."""
+    """Pre-allocated gather of the bands to rank 0.  Without a process group (dist=None) the frame is already whole."""
 
     def __init__(self, height, width, rank, world, device, dist=None):
         self.height, self.width, self.rank, self.world, self.dist = height, width, rank, world, dist
@@ -45,12 +45,12 @@ class BandGather:
         self.row_floats = BAND_ROWS * width * 3
         per_rank = self.bands_pad // world
         self.parts = None
-        if world > 1 and rank == 0:
+        if dist is not None and rank == 0:
             self.parts = [torch.empty((per_rank, self.row_floats), dtype=torch.float32, device=device) for _ in range(world)]
 
     def __call__(self, frame):
         """frame: alloc_frame(...) tensor holding this rank's bands.  On return rank 0's frame is complete."""
-        if self.world == 1:
+        if self.dist is None:
             return frame
         fv = frame.view(self.bands_pad, self.row_floats)
         mine = fv[self.rank::self.world].contiguous()
