@@ -408,6 +408,8 @@ int host_build(rt_ads* a) {
         HIP_TRY(a->d_flat_tris.reserve(flat.flat_tris.size() + 4));
         HIP_TRY(hipMemcpy(a->d_flat_nodes.p, flat.flat_nodes.data(), flat.flat_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(a->d_flat_tris.p, flat.flat_tris.data(), flat.flat_tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+        // the pass over this array runs in blocks of 4 records; the padding records list no leaf (mask 0)
+        HIP_TRY(hipMemset(a->d_flat_tris.p + flat.flat_tris.size(), 0, 4 * sizeof(LeafTri)));
     }
     if (n) {
         std::vector<LeafTri> g(n);

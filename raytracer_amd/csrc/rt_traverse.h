@@ -135,39 +135,45 @@ __device__ __forceinline__ Block48 sload48(cu32_p p) {
 
 constexpr int kTriChunk = 4;  // triangle records per scalar-load group (arrays are padded by this many records)
 
-// Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.
+// One record of a leaf's 4-record block (record j, global slot `slot`) for the lanes in `mine`.
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32_t slot, lanemask mine, f3 o, f3 d, float t_limit,
+                                         HitState& h) {
+    if (mine == 0) return;
+    const f3 a = mk(RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2));
+    const f3 e1 = mk(RT_F(blk, 12 * j + 3), RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5));
+    const f3 e2 = mk(RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8));
+    float t = RT_INF;
+    const lanemask hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
+    if (hit == 0) return;
+    if (ANY) {
+        h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+    } else {
+        // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the smaller global slot.
+        const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
+        if (better == 0) return;
+        const uint32_t tri = RT_W(blk, 12 * j + 9);
+        const bool b = lane_of(better);
+        h.t = b ? t : h.t;
+        h.slot = b ? slot : h.slot;
+        h.tri = b ? tri : h.tri;
+    }
+}
+
+// Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.  Records are read four at a time;
+// those past the leaf's end (the next leaf's, or the array's padding) get an empty lane mask.
 template <bool ANY, bool CULL>
 __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, lanemask mine, f3 o, f3 d, float t_limit,
                                            HitState& h) {
     cu32_p base = as_const_u(T.slots);
     for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)(begin + k0) * 12);
-#pragma unroll
-        for (int j = 0; j < kTriChunk; ++j) {
-            if (k0 + j >= count) break;
-            const uint32_t slot = begin + k0 + j;
-            const f3 a = mk(RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2));
-            const f3 e1 = mk(RT_F(blk, 12 * j + 3), RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5));
-            const f3 e2 = mk(RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8));
-            float t = RT_INF;
-            const lanemask hit = ray_triangle<CULL>(mine, o, d, a, e1, e2, t);
-            if (hit == 0) continue;
-            if (ANY) {
-                h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
-                mine &= ~h.found;
-                if (mine == 0) return;
-            } else {
-                // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the
-                // smaller global slot.
-                const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
-                if (better == 0) continue;
-                const uint32_t tri = RT_W(blk, 12 * j + 9);
-                const bool b = lane_of(better);
-                h.t = b ? t : h.t;
-                h.slot = b ? slot : h.slot;
-                h.tri = b ? tri : h.tri;
-            }
-        }
+        const lanemask none = 0;
+        leaf_one<ANY, CULL>(blk, 0, begin + k0 + 0, ANY ? (mine & ~h.found) : mine, o, d, t_limit, h);
+        leaf_one<ANY, CULL>(blk, 1, begin + k0 + 1, k0 + 1 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL>(blk, 2, begin + k0 + 2, k0 + 2 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL>(blk, 3, begin + k0 + 3, k0 + 3 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        if (ANY && (mine & ~h.found) == 0) return;  // every ray that reached this leaf is decided
     }
 }
 
@@ -178,39 +184,44 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
 // answers and closest distances are unchanged.  The reference's tie rule (first in candidate-list order) becomes:
 // smaller ordinal of the first reached leaf that lists the triangle, then smaller triangle index (leaf lists are
 // ascending); the loop runs in ascending j, so an equal-t later triangle wins only with a smaller first leaf.
+// One triangle record of the small-tree pass (record jj of the 4-record block, triangle index j).
 template <bool ANY, bool CULL>
-__device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask alive, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
+__device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint32_t j, lanemask alive, uint32_t reach, f3 o, f3 d,
+                                         float t_limit, HitState& h) {
+    const uint32_t lm = RT_W(blk, 12 * jj + 10);
+    const lanemask need = alive & ballot64((reach & lm) != 0);
+    if (need == 0) return;
+    const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
+    const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
+    const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
+    float t = RT_INF;
+    const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
+    if (hit == 0) return;
+    if (ANY) {
+        h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+    } else {
+        const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);  // garbage on lanes outside `need`
+        const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
+        if (better == 0) return;
+        const bool b = lane_of(better);
+        h.t = b ? t : h.t;
+        h.slot = b ? first_leaf : h.slot;
+        h.tri = b ? j : h.tri;
+    }
+}
+
+template <bool ANY, bool CULL>
+__device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
     cu32_p base = as_const_u(T.flat_tris);
     const uint32_t n = T.n_flat_tris;
+    // The array is padded to whole blocks with records whose leaf mask is 0: no lane ever needs them.
     for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)j0 * 12);
-#pragma unroll
-        for (int jj = 0; jj < kTriChunk; ++jj) {
-            const uint32_t j = j0 + jj;
-            if (j >= n) break;
-            const uint32_t lm = RT_W(blk, 12 * jj + 10);
-            const lanemask need = alive & ballot64((reach & lm) != 0);
-            if (need == 0) continue;
-            const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
-            const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
-            const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
-            float t = RT_INF;
-            const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
-            if (hit == 0) continue;
-            if (ANY) {
-                h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
-                alive &= ~h.found;
-                if (alive == 0) return;
-            } else {
-                const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);  // garbage on lanes outside `need`
-                const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
-                if (better == 0) continue;
-                const bool b = lane_of(better);
-                h.t = b ? t : h.t;
-                h.slot = b ? first_leaf : h.slot;
-                h.tri = b ? j : h.tri;
-            }
-        }
+        flat_one<ANY, CULL>(blk, 0, j0 + 0, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL>(blk, 1, j0 + 1, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL>(blk, 2, j0 + 2, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL>(blk, 3, j0 + 3, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        if (ANY && (all & ~h.found) == 0) return;  // every ray of the wave is decided
     }
 }
 
