@@ -120,7 +120,7 @@ constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
-    bool built = false, shading_set = false, has_normals = false, branching = false, use_flat = true;
+    bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
     int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
@@ -831,7 +831,8 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         if (material_ids[i] < 0 || (uint32_t)material_ids[i] >= n_mat)
             return fail(RT_ERR_INVALID, "triangle %llu has material id %d outside [0,%u)", (unsigned long long)i, material_ids[i], n_mat);
     std::vector<MatDev> mats(std::max<uint32_t>(n_mat, 1));
-    a->branching = false;
+    a->branching = false;      // some material spawns two secondary rays per hit
+    a->branching_any = false;  // some material spawns a secondary ray at all
     for (uint32_t m = 0; m < n_mat; ++m) {
         const float* f = materials + (size_t)m * 18;
         MatDev& d = mats[m];
@@ -846,6 +847,7 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         d.has_specular = !eq_eps(mk(f[6], f[7], f[8]), mk(0, 0, 0));        // renderer.cc:179
         d.has_transmittance = !eq_eps(mk(f[9], f[10], f[11]), mk(0, 0, 0)); // renderer.cc:185
         if (d.has_specular && d.has_transmittance) a->branching = true;
+        if (d.has_specular || d.has_transmittance) a->branching_any = true;
     }
     // light list: emissive triangles in Build order (obj_loader.cc:188-191)
     std::vector<uint32_t> light_tri;
@@ -1031,12 +1033,19 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             if (L == 0) st.primary_rays += 0;  // counted below from the valid pixel count
             else st.secondary_rays += n;
             levels = L + 1;
-            if (int rc = read_counters(a, L, stream)) return rc;
-            const uint32_t n_work = a->h_counters[CNT_WORK];
-            if (n_work == 0) break;
+            // Camera rays mostly hit something, so for level 0 the hit count stays on the device: the any-hit and
+            // shading passes are launched for the level's ray count (an upper bound; surplus blocks leave at once)
+            // and the level costs one host synchronisation (for the size of the next level) instead of two.
+            // Deeper levels often hit nothing at all; there the count is read first.
+            uint32_t n_work = n;
+            if (L > 0) {
+                if (int rc = read_counters(a, L, stream)) return rc;
+                n_work = a->h_counters[CNT_WORK];
+                if (n_work == 0) break;
+            }
             RayRec* next_rays = nullptr;
             uint32_t next_cap = 0;
-            if (L + 1 < max_levels) {
+            if (L + 1 < max_levels && a->branching_any) {
                 const uint64_t want = (uint64_t)n_work * (a->branching ? 2ull : 1ull);
                 if (want > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "recursion level too large");
                 HIP_TRY(a->levels[L + 1].reserve((uint32_t)want, true));
