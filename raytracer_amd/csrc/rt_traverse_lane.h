@@ -128,43 +128,50 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
         }
         if (ballot64(active) == 0) break;
-        // ---- phase B: lanes that hold a leaf test its triangles, one per step, the next record already in flight
-        // (the slot array is padded, so reading one record past a leaf's end is harmless).  The phase ends when all
-        // leaves are done, or earlier once few lanes are still testing while others wait for a new leaf.
+        // ---- phase B: lanes that hold a leaf test its triangles, two per step (the second only if the leaf has one),
+        // the next pair already in flight (the slot array is padded, so reading records past a leaf's end is
+        // harmless).  The phase ends when all leaves are done, or earlier once few lanes are still testing while
+        // others wait for a new leaf.
         const float4* r = reinterpret_cast<const float4*>(T.slots + (leaf_left != 0 ? leaf_slot : 0u));
-        float4 n0 = r[0], n1 = r[1], n2 = r[2];
+        float4 n0 = r[0], n1 = r[1], n2 = r[2], n3 = r[3], n4 = r[4], n5 = r[5];
         for (;;) {
             const lanemask busy = ballot64(leaf_left != 0);
             if (busy == 0) break;
             const lanemask idle = ballot64(active && leaf_left == 0);
             if (__builtin_popcountll(busy) * kLanePhaseRatio < __builtin_popcountll(idle)) break;
-            const float4 r0 = n0, r1 = n1, r2 = n2;
-            const float4* q = reinterpret_cast<const float4*>(T.slots + (leaf_left > 1 ? leaf_slot + 1u : 0u));
-            n0 = q[0];
-            n1 = q[1];
-            n2 = q[2];
-            const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-            float t = RT_INF;
-            const lanemask hit = ray_triangle<CULL>(busy, o, d, a, e1, e2, t);
-            if (hit != 0) {
-                if (ANY) {
-                    const bool f = lane_of(hit & ballot64(t < t_limit));  // renderer.cc:302
-                    found = found || f;
-                    if (f) {  // this ray is decided
-                        active = false;
-                        leaf_left = 1;  // ends the lane's leaf below
+            const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4, r5 = n5;
+            const float4* q = reinterpret_cast<const float4*>(T.slots + (leaf_left > 2 ? leaf_slot + 2u : 0u));
+            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; n4 = q[4]; n5 = q[5];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const lanemask on = k == 0 ? busy : ballot64(leaf_left != 0);
+                if (on == 0) break;
+                const f3 a = k == 0 ? mk(r0.x, r0.y, r0.z) : mk(r3.x, r3.y, r3.z);
+                const f3 e1 = k == 0 ? mk(r0.w, r1.x, r1.y) : mk(r3.w, r4.x, r4.y);
+                const f3 e2 = k == 0 ? mk(r1.z, r1.w, r2.x) : mk(r4.z, r4.w, r5.x);
+                const uint32_t tri = __float_as_uint(k == 0 ? r2.y : r5.y);
+                float t = RT_INF;
+                const lanemask hit = ray_triangle<CULL>(on, o, d, a, e1, e2, t);
+                if (hit != 0) {
+                    if (ANY) {
+                        const bool f = lane_of(hit & ballot64(t < t_limit));  // renderer.cc:302
+                        found = found || f;
+                        if (f) {  // this ray is decided
+                            active = false;
+                            leaf_left = 1;  // ends the lane's leaf below
+                        }
+                    } else {
+                        // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
+                        const bool b = lane_of(hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(leaf_slot < h.slot))));
+                        h.t = b ? t : h.t;
+                        h.slot = b ? leaf_slot : h.slot;
+                        h.tri = b ? tri : h.tri;
                     }
-                } else {
-                    // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
-                    const bool b = lane_of(hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(leaf_slot < h.slot))));
-                    h.t = b ? t : h.t;
-                    h.slot = b ? leaf_slot : h.slot;
-                    h.tri = b ? __float_as_uint(r2.y) : h.tri;
                 }
-            }
-            if (leaf_left != 0) {
-                ++leaf_slot;
-                --leaf_left;
+                if (leaf_left != 0) {
+                    ++leaf_slot;
+                    --leaf_left;
+                }
             }
         }
     }
