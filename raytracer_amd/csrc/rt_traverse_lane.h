@@ -24,6 +24,13 @@ namespace rt {
 
 constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
 constexpr int kLaneBlock = 256;      // threads per block of the kernels that use this traversal
+#ifndef RT_LANE_A_NUM
+#define RT_LANE_A_NUM 1
+#define RT_LANE_A_DEN 2
+#endif
+#ifndef RT_LANE_PAIR_PHASE
+#define RT_LANE_PAIR_PHASE 1
+#endif
 #ifndef RT_LANE_PHASE_RATIO
 #define RT_LANE_PHASE_RATIO 2
 #endif
@@ -32,7 +39,27 @@ constexpr int kLanePhaseRatio = RT_LANE_PHASE_RATIO;
 
 struct LaneStackLds {
     uint32_t e[kLaneMaxLevels][kLaneBlock];
+    uint32_t hd[kLaneBlock];  // per wave: which lane's leaf starts at each position of the current 64-pair chunk
 };
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    const int lane = (int)__lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
+    const int lane = (int)__lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x = x < y ? y : x;
+    }
+    return x;
+}
 
 // Slab tests of the 8 octants of node `rec` for this lane's ray: bit o set iff octant o is non-empty and passes
 // (collision_detection.h:71-86 per octant; the plane products are shared between octants, see NodeRec).
@@ -98,7 +125,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             const lanemask searching = ballot64(active && leaf_left == 0);
             if (searching == 0) break;
             const lanemask holding = ballot64(leaf_left != 0);
-            if (__builtin_popcountll(searching) * kLanePhaseRatio < __builtin_popcountll(holding)) break;
+            if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
             if (active && leaf_left == 0) {
                 if (cur_pending == 0) {
                     if (sp == 0) {
@@ -128,6 +155,80 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
         }
         if (ballot64(active) == 0) break;
+#if RT_LANE_PAIR_PHASE
+        // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane owns
+        // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
+        // lane i of the wave tests pair base + i: it fetches the owner's ray through lane shuffles and the triangle
+        // record itself -- neighbouring lanes read neighbouring records, so the loads coalesce -- and the owners
+        // collect the results from the ballot (any-hit) or from the hit lanes of their range (closest hit; ranges
+        // are in slot order, so the tie rule is the lane order).
+        {
+            const uint32_t lane = __lane_id();
+            const uint32_t cnt = leaf_left;
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            const uint32_t excl = incl - cnt;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            volatile uint32_t* hd = &stk.hd[tid & ~63u];
+            lanemask decided = 0;  // any-hit: owners that found an occluder earlier in this round
+            for (uint32_t base = 0; base < total; base += 64) {
+                hd[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (cnt != 0 && excl >= base && excl < base + 64) hd[excl - base] = lane + 1;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t own = hd[lane];
+                __builtin_amdgcn_wave_barrier();
+                const lanemask cont = ballot64(cnt != 0 && excl < base && incl > base);  // a leaf continuing from the last chunk
+                const uint32_t carry = cont ? (uint32_t)__builtin_ctzll(cont) + 1u : 0u;
+                own = wave_inclusive_max(own);
+                own = own < carry ? carry : own;
+                const uint32_t p = base + lane;
+                const bool pair = p < total;
+                const uint32_t L = pair ? own - 1u : lane;
+                const uint32_t o_excl = __shfl(excl, (int)L, 64), o_slot = __shfl(leaf_slot, (int)L, 64);
+                const f3 ro = mk(__shfl(o.x, (int)L, 64), __shfl(o.y, (int)L, 64), __shfl(o.z, (int)L, 64));
+                const f3 rd = mk(__shfl(d.x, (int)L, 64), __shfl(d.y, (int)L, 64), __shfl(d.z, (int)L, 64));
+                const uint32_t slot = o_slot + (p - o_excl);
+                const bool on = pair && !((decided >> L) & 1ull);
+                const float4* r = reinterpret_cast<const float4*>(T.slots + (on ? slot : 0u));
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                float t = RT_INF;
+                const lanemask hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                if (hit == 0) continue;
+                // this lane's leaf covers positions [lo, hi) of the chunk
+                const bool here = cnt != 0 && excl < base + 64 && incl > base;
+                const uint32_t lo = excl > base ? excl - base : 0u;
+                const uint32_t hi = incl - base < 64u ? incl - base : 64u;
+                const lanemask below_hi = hi >= 64u ? ~0ull : ((1ull << hi) - 1ull);
+                const lanemask range = here ? (below_hi & ~((1ull << lo) - 1ull)) : 0ull;
+                if (ANY) {
+                    const float rlim = __shfl(t_limit, (int)L, 64);
+                    const lanemask good = hit & ballot64(t < rlim);  // renderer.cc:302
+                    const bool f = (good & range) != 0;
+                    found = found || f;
+                    decided |= ballot64(f);
+                } else {
+                    const uint32_t tri = __float_as_uint(r2.y);
+                    lanemask m = hit & range;
+                    while (ballot64(m != 0) != 0) {
+                        const bool has = m != 0;
+                        const uint32_t c = has ? (uint32_t)__builtin_ctzll(m) : lane;
+                        m &= m - 1ull;
+                        const float tc = __shfl(t, (int)c, 64);
+                        const uint32_t sc = __shfl(slot, (int)c, 64), trc = __shfl(tri, (int)c, 64);
+                        // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
+                        const bool b = has && (tc < h.t || (tc == h.t && sc < h.slot));
+                        h.t = b ? tc : h.t;
+                        h.slot = b ? sc : h.slot;
+                        h.tri = b ? trc : h.tri;
+                    }
+                }
+            }
+            if (ANY && found) active = false;  // this ray is decided
+            leaf_left = 0;
+        }
+    }
+#else
         // ---- phase B: lanes that hold a leaf test its triangles, two per step (the second only if the leaf has one),
         // the next pair already in flight (the slot array is padded, so reading records past a leaf's end is
         // harmless).  The phase ends when all leaves are done, or earlier once few lanes are still testing while
@@ -175,6 +276,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
         }
     }
+#endif
     if (ANY) h.found = ballot64(found);
 }
 
