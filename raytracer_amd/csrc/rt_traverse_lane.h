@@ -4,9 +4,12 @@
 // work is the UNION of what the 64 rays reach.  Rays that leave a finely subdivided surface towards 64 different
 // random points of an area light share almost nothing, and the union is then tens of times one ray's work.
 // Here every lane walks its own ray: its own descent, its own leaves, vector loads instead of scalar loads.
-// The wave alternates between two phases ("while-while"): lanes that need a leaf descend (one octant per
-// step: either it is an internal node, whose 8 octants are slab-tested at once, or it is a leaf), then lanes that
-// hold a leaf test one triangle per step.  The work of a wave is the MAXIMUM over its lanes, not the union.
+// The wave alternates between two phases.  Descent: lanes that need a leaf take one octant per step (either an
+// internal node, whose 8 octants are slab-tested at once, or a leaf); the phase ends when enough lanes hold a leaf.
+// Leaf work: the triangles of all held leaves form one list of (ray, triangle) pairs that the 64 lanes test 64 at a
+// time, whichever lane owns the ray -- full lanes whatever the leaf sizes, and neighbouring lanes read neighbouring
+// triangle records.  The descent work of a wave is the MAXIMUM over its lanes, its leaf work the SUM / 64; neither
+// is the union.
 //
 // Candidate set, arithmetic and tie rule are the same as in rt_traverse.h (see there): every leaf reached through
 // passing slab tests contributes all its triangle references; equal t keeps the smaller global leaf slot.
@@ -24,18 +27,12 @@ namespace rt {
 
 constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
 constexpr int kLaneBlock = 256;      // threads per block of the kernels that use this traversal
+// The descent phase is left once the lanes holding a leaf outnumber RT_LANE_A_NUM / RT_LANE_A_DEN of the lanes still
+// searching (measured best on a 1.3 M-triangle scene: 1 / 2).
 #ifndef RT_LANE_A_NUM
 #define RT_LANE_A_NUM 1
 #define RT_LANE_A_DEN 2
 #endif
-#ifndef RT_LANE_PAIR_PHASE
-#define RT_LANE_PAIR_PHASE 1
-#endif
-#ifndef RT_LANE_PHASE_RATIO
-#define RT_LANE_PHASE_RATIO 2
-#endif
-// a phase is left early when the lanes it still serves are fewer than 1/kLanePhaseRatio of the lanes waiting for the other phase
-constexpr int kLanePhaseRatio = RT_LANE_PHASE_RATIO;
 
 struct LaneStackLds {
     uint32_t e[kLaneMaxLevels][kLaneBlock];
@@ -155,7 +152,6 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
         }
         if (ballot64(active) == 0) break;
-#if RT_LANE_PAIR_PHASE
         // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane owns
         // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
         // lane i of the wave tests pair base + i: it fetches the owner's ray through lane shuffles and the triangle
@@ -228,55 +224,6 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             leaf_left = 0;
         }
     }
-#else
-        // ---- phase B: lanes that hold a leaf test its triangles, two per step (the second only if the leaf has one),
-        // the next pair already in flight (the slot array is padded, so reading records past a leaf's end is
-        // harmless).  The phase ends when all leaves are done, or earlier once few lanes are still testing while
-        // others wait for a new leaf.
-        const float4* r = reinterpret_cast<const float4*>(T.slots + (leaf_left != 0 ? leaf_slot : 0u));
-        float4 n0 = r[0], n1 = r[1], n2 = r[2], n3 = r[3], n4 = r[4], n5 = r[5];
-        for (;;) {
-            const lanemask busy = ballot64(leaf_left != 0);
-            if (busy == 0) break;
-            const lanemask idle = ballot64(active && leaf_left == 0);
-            if (__builtin_popcountll(busy) * kLanePhaseRatio < __builtin_popcountll(idle)) break;
-            const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4, r5 = n5;
-            const float4* q = reinterpret_cast<const float4*>(T.slots + (leaf_left > 2 ? leaf_slot + 2u : 0u));
-            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; n4 = q[4]; n5 = q[5];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const lanemask on = k == 0 ? busy : ballot64(leaf_left != 0);
-                if (on == 0) break;
-                const f3 a = k == 0 ? mk(r0.x, r0.y, r0.z) : mk(r3.x, r3.y, r3.z);
-                const f3 e1 = k == 0 ? mk(r0.w, r1.x, r1.y) : mk(r3.w, r4.x, r4.y);
-                const f3 e2 = k == 0 ? mk(r1.z, r1.w, r2.x) : mk(r4.z, r4.w, r5.x);
-                const uint32_t tri = __float_as_uint(k == 0 ? r2.y : r5.y);
-                float t = RT_INF;
-                const lanemask hit = ray_triangle<CULL>(on, o, d, a, e1, e2, t);
-                if (hit != 0) {
-                    if (ANY) {
-                        const bool f = lane_of(hit & ballot64(t < t_limit));  // renderer.cc:302
-                        found = found || f;
-                        if (f) {  // this ray is decided
-                            active = false;
-                            leaf_left = 1;  // ends the lane's leaf below
-                        }
-                    } else {
-                        // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
-                        const bool b = lane_of(hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(leaf_slot < h.slot))));
-                        h.t = b ? t : h.t;
-                        h.slot = b ? leaf_slot : h.slot;
-                        h.tri = b ? tri : h.tri;
-                    }
-                }
-                if (leaf_left != 0) {
-                    ++leaf_slot;
-                    --leaf_left;
-                }
-            }
-        }
-    }
-#endif
     if (ANY) h.found = ballot64(found);
 }
 
