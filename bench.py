@@ -197,6 +197,18 @@ def main():
             flops_closest = 3 + 18 * b_cl + 52 * t_cl
             out["reference_work_per_ray"] = {"any_hit": {"B": b_any, "T": t_any, "flops": flops_any},
                                              "closest_hit": {"B": b_cl, "T": t_cl, "flops": flops_closest}}
+        if world == 1:
+            # the same frame with the framebuffer handed back in host memory (device -> host copy inside the call);
+            # reported beside `value`, never as it
+            host_img = np.empty((H, W, 3), np.float32)
+            ads.render(cfg, out=host_img)
+            h0 = time.perf_counter()
+            n_host = max(1, min(args.steps, 5))
+            for _ in range(n_host):
+                _, hst = ads.render(cfg, out=host_img)
+            host_s = (time.perf_counter() - h0) / n_host
+            out["host_framebuffer"] = {"Mrays_per_s": hst.rays / host_s / 1e6, "ms_per_frame": host_s * 1e3,
+                                       "note": "rt_render with RT_MEM_HOST output: adds the PCIe copy of the frame"}
         kernel_rate = shadow_rays / max(shadow_ms * 1e-3, 1e-12) / 1e6
         roof = {"bound": "valu", "kernel": "k_shadow (any-hit pass: area-light shadow rays)", "achieved": None,
                 "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,

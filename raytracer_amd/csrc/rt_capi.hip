@@ -1106,6 +1106,9 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     }
     if (mem == RT_MEM_HOST) {
         const int bands = (c->height + 7) / 8;
+        if (c->band_world == 1) {  // the whole frame in one copy
+            HIP_TRY(hipMemcpyAsync(out_rgb, d_out, frame_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+        } else
         for (int b = c->band_rank; b < bands; b += c->band_world) {
             const size_t row0 = (size_t)b * 8, rows = (size_t)std::min(8, c->height - b * 8);
             const size_t off = row0 * c->width * 3, cnt = rows * c->width * 3;
