@@ -344,6 +344,25 @@ def test_errors(rt, scenes):
         g.render(rt.make_render_config(fov=0.6, width=8, height=8, shading="smooth", **CAMERAS["original"]))
     with pytest.raises(RuntimeError, match="samples_per_pixel"):
         g.render(rt.make_render_config(fov=0.6, width=8, height=8, spp=0, **CAMERAS["original"]))
+    # C ABI argument checks
+    import ctypes as C
+    from raytracer_amd import _capi
+    h = C.c_void_p()
+    bad = _capi.AdsConfig(C.sizeof(_capi.AdsConfig), 0, 16, 10, 7)
+    assert _capi.lib().rt_ads_create(C.byref(bad), C.byref(h)) == -1 and b"builder" in _capi.lib().rt_last_error()
+    bad = _capi.AdsConfig(C.sizeof(_capi.AdsConfig) - 4, 0, 16, 10, 0)
+    assert _capi.lib().rt_ads_create(C.byref(bad), C.byref(h)) == -1 and b"struct_size" in _capi.lib().rt_last_error()
+    # limits are reported, never silently exceeded: a tree deeper than the traversal stacks allow
+    # (two triangles that share one vertex: the octant around the vertex is subdivided down to max_depth)
+    v = [0.3, 0.2, 0.1]
+    two = np.array([[v, [1, 0, 0], [0, 1, 0]], [v, [-1, 0, 0.5], [0, -1, 0.7]]], np.float32)
+    for builder in ("host", "device"):
+        deep = rt.GpuOctree({"max_triangles_per_BB": 1, "max_depth": 24, "builder": builder})
+        with pytest.raises(RuntimeError, match="deep"):
+            deep.Build(two)
+        ok = rt.GpuOctree({"max_triangles_per_BB": 1, "max_depth": 16, "builder": builder})
+        ok.Build(two)
+        assert ok.tree_stats()["max_depth"] == 16
 
 
 def test_dropin_behind_reference_ads_interface(scenes, tmp_path):

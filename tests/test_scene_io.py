@@ -117,3 +117,9 @@ def test_renderer_config_errors():
         rr.Renderer({k: v for k, v in good.items() if k != "max_distance"})
     assert rr.Renderer(dict(good, acceleratied_data_structure=dict(good["acceleratied_data_structure"], name="octree"))) \
         .acceleration_data_structure_ == 1
+    # the optional "builder" key of the GPU data structure is validated before any device is touched
+    from raytracer_amd.ads import GpuOctree
+    with pytest.raises(RuntimeError, match="Invalid builder"):
+        GpuOctree(dict(good["acceleratied_data_structure"], builder="fpga"))
+    with pytest.raises(KeyError):
+        GpuOctree({"max_depth": 10})
