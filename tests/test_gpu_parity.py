@@ -310,6 +310,62 @@ def test_render_is_partition_independent(rt, scenes):
         assert np.array_equal(bits(out), bits(full))
 
 
+def test_full_size_frame_properties(rt, orc, scenes, monkeypatch):
+    """The headline configuration at its full size (Cornell-Original, Blinn-Phong, 16 light samples, 1920x1080):
+    the reference's ray count, the oracle's pixels on a band of rows, and size-independent properties -- every
+    traversal form renders the same bits, a 4-way band split reassembles to the same frame, two runs are identical."""
+    sc = scenes["original"]
+    cam = CAMERAS["original"]
+    kw = dict(fov=0.6, width=1920, height=1080, spt=16, render_type="blinn_phong", shading="flat", **cam)
+    g = build(rt, sc)
+    cfg = rt.make_render_config(**kw)
+    full, st = g.render(cfg)
+    assert st.rays == 77841000  # "Search method call count" of the reference binary for this frame (golden K-table)
+    again, st2 = g.render(cfg)
+    assert np.array_equal(bits(again), bits(full)) and st2.rays == st.rays
+    # rows 536..543 against the oracle (compat aspect: every row is the same scanline, the RNG differs per pixel)
+    ref, _, _, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(536, 544), **kw), want_hits=False)
+    assert np.abs(full[536:544] - ref[536:544]).max() <= 1.0 / 255.0
+    # the other traversal forms
+    for env in ({"RT_DISABLE_SMALL_TREE": "1"}, {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g2 = build(rt, sc)
+        img2, s2 = g2.render(cfg)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(bits(img2), bits(full)) and s2.rays == st.rays, env
+    # 4 ranks' bands
+    out = np.zeros_like(full)
+    rays = 0
+    for r in range(4):
+        _, sr = g.render(rt.make_render_config(band_rank=r, band_world=4, **kw), out=out)
+        rays += sr.rays
+    assert np.array_equal(bits(out), bits(full)) and rays == st.rays
+
+
+def test_large_tree_frame_properties(rt, monkeypatch):
+    """The 1,310,754-triangle scene at a size no CPU check finishes quickly (1920x1080, true aspect): the frame must not
+    depend on where the tree was built or on which traversal form walks it."""
+    s = synthetic_scene(8)
+    cam = CAMERAS["original"]
+    cfg = rt.make_render_config(fov=0.6, width=1920, height=1080, spt=1, render_type="phong", shading="flat", aspect_mode=1, **cam)
+    frames = []
+    for builder, traversal in (("device", "auto"), ("host", "auto"), ("device", "wave"), ("device", "lane")):
+        monkeypatch.setenv("RT_TRAVERSAL", traversal)
+        g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10, "builder": builder})
+        g.Build(s.pos)
+        g.set_shading(None, s.matid, s.materials)
+        img, st = g.render(cfg)
+        frames.append((img, st.rays, st.shadow_rays, st.secondary_rays))
+        g.close()
+    monkeypatch.delenv("RT_TRAVERSAL")
+    for img, rays, shadow, secondary in frames[1:]:
+        assert np.array_equal(bits(img), bits(frames[0][0]))
+        assert (rays, shadow, secondary) == frames[0][1:]
+    assert frames[0][1] > 2 * 1920 * 1080
+
+
 def test_renderer_mirror_writes_the_reference_ppm(rt, orc, scenes, tmp_path):
     """Renderer(config).RenderScene(...) with the reference's config keys: the PPM file it writes is byte-identical to
     the oracle's for an RNG-free render type (reflections included)."""
