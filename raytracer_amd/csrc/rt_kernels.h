@@ -317,17 +317,17 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 }
 
 // The any-hit pass: every shadow / area-light ray of every hit of one level (renderer.cc:217-219, 288-313).
-// A hit owns 2^gshift neighbouring lanes (the samples-per-light count rounded up to a power of two, at most 64):
-// lane `sub` of the group traces sample sub, sub + 2^gshift, ... of each light in turn, so the 64 rays a wave
-// traverses together leave from 64 >> gshift surface points towards one light, and a launch has enough waves to
-// fill the chip even for a few thousand hits.  The result is one visibility bit per (light, sample):
-// vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1 if not shadowed (hit j innermost); the bits of a word come
-// from one ballot, so no two lanes ever write the same word.
+// A hit owns 2^gshift neighbouring lanes.  The (light, sample) pairs of the hit are numbered q = light * 2^pshift +
+// sample (2^pshift = the samples-per-light count rounded up to a power of two) and lane `sub` of the group traces
+// q = sub, sub + 2^gshift, ...: the 64 rays a wave traverses together leave from 64 >> gshift surface points towards
+// the lights, rays of one origin side by side, and a launch has enough waves to fill the chip even for a few thousand
+// hits.  The result is one visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1
+// if not shadowed (hit j innermost); the bits of a word come from one ballot, so no two lanes write the same word.
 template <bool CULL, bool LANE>
 __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
-                                                uint32_t gshift, uint32_t* __restrict__ counters) {
+                                                uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters) {
     __shared__ LaneStackSlot<LANE> lds;
     const uint32_t group = 1u << gshift;
     const uint32_t j = (uint32_t)(((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> gshift);
@@ -349,32 +349,36 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
     }
     const f3 P = o + (d * t);  // renderer.cc:146
     const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
-    // the lanes whose ballot bits form one visibility word: a whole group, or 32 lanes of a 64-lane group
-    const uint32_t word_lanes = group < 32u ? group : 32u;
+    // renderer.cc:212-214: the light loop ends at the light the hit triangle itself is
+    const uint32_t lights_traced = !valid ? 0u : ((light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights);
+    // the lanes whose ballot bits form one visibility word: the samples of one light, or 32 of them
+    const uint32_t per_light = 1u << pshift;
+    const uint32_t word_lanes = per_light < 32u ? per_light : 32u;
     const uint32_t word_first_lane = (uint32_t)__lane_id() & ~(word_lanes - 1u);
     const uint32_t word_mask = word_lanes == 32u ? 0xffffffffu : ((1u << word_lanes) - 1u);
     const bool writer = (sub & (word_lanes - 1u)) == 0u;
-    bool live = valid;  // still inside render_local_ilumination's light loop
-    for (uint32_t l = 0; l < S.n_lights; ++l) {
-        if (light_eq == (int32_t)l) live = false;  // renderer.cc:212-214: the hit triangle is this light
-        if (ballot64(live) == 0) break;
-        const LightDev L = S.lights[l];
-        for (uint32_t s0 = 0; s0 < (uint32_t)F.spt; s0 += group) {
-            const uint32_t smp = s0 + sub;
-            const bool on = live && smp < (uint32_t)F.spt;
-            const f3 p_l = light_sample(L, pre, l, smp);
-            // renderer.cc:289-290
-            const f3 to_l = p_l - P;
-            const float dist = length(to_l);
-            const f3 d_l = normalize(to_l);
-            HitState h;
-            const lanemask on_mask = ballot64(on);
-            trace<true, CULL, LANE>(S.tree, lds, on, P, d_l, dist, h);
-            const lanemask unshadowed = on_mask & ~h.found;
-            const uint32_t word = (smp >> 5);
-            if (live && writer && word < words)
-                vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
-        }
+    const uint32_t q_end = S.n_lights << pshift;
+    for (uint32_t q0 = 0; q0 < q_end; q0 += group) {
+        const uint32_t q = q0 + sub;
+        const uint32_t l = q >> pshift, smp = q & (per_light - 1u);
+        const bool lit = l < lights_traced;
+        const bool on = lit && smp < (uint32_t)F.spt;
+        const lanemask on_mask = ballot64(on);
+        if (on_mask == 0) continue;
+        // one light per pass (group == samples per light): its record is wave-uniform and comes through scalar loads
+        const uint32_t l_load = gshift == pshift ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
+        const LightDev& L = S.lights[l_load];
+        const f3 p_l = light_sample(L, pre, l, smp);
+        // renderer.cc:289-290
+        const f3 to_l = p_l - P;
+        const float dist = length(to_l);
+        const f3 d_l = normalize(to_l);
+        HitState h;
+        trace<true, CULL, LANE>(S.tree, lds, on, P, d_l, dist, h);
+        const lanemask unshadowed = on_mask & ~h.found;
+        const uint32_t word = smp >> 5;
+        if (lit && writer && word < words)
+            vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
     }
 }
 
