@@ -1062,12 +1062,12 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 // lanes per hit in the any-hit pass: the (light, sample) pairs of a hit, samples padded to a power of
                 // two per light, side by side in at most 64 lanes
                 uint32_t pshift = 0, gshift = 0;
-                while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 6) ++pshift;
+                while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 30) ++pshift;
                 // Per-lane traversal gains from rays of one origin side by side (all lights of a hit in one wave);
                 // the wave-together forms measured faster with one light per pass (a narrower bundle of rays).
                 const bool lanes = lane_mode(a, false);
                 while (lanes && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
-                if (gshift < pshift) gshift = pshift;
+                if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 const dim3 grid_a((uint32_t)((((uint64_t)n_work << gshift) + 255) / 256));
                 RT_LAUNCH2(k_shadow, F.cull != 0, lane_mode(a, false), grid_a, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
                            lv.work.p, lv.vis.p, words, pshift, gshift, cnt);

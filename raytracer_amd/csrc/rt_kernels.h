@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
         const lanemask on_mask = ballot64(on);
         if (on_mask == 0) continue;
         // one light per pass (group == samples per light): its record is wave-uniform and comes through scalar loads
-        const uint32_t l_load = gshift == pshift ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
+        const uint32_t l_load = gshift <= pshift ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
         const LightDev& L = S.lights[l_load];
         const f3 p_l = light_sample(L, pre, l, smp);
         // renderer.cc:289-290

@@ -344,6 +344,30 @@ def test_full_size_frame_properties(rt, orc, scenes, monkeypatch):
     assert np.array_equal(bits(out), bits(full)) and rays == st.rays
 
 
+@pytest.mark.parametrize("spt", [3, 5, 33, 70])
+@pytest.mark.parametrize("mode", ["auto", "lane"])
+def test_light_sample_layouts(rt, orc, scenes, monkeypatch, spt, mode):
+    """Sample counts that are not powers of two, exceed one visibility word (32) or one wave (64), with three lights
+    (one more triangle made emissive): the any-hit pass spreads (light, sample) pairs over lane groups differently
+    in each case, the image and the ray counts must not notice."""
+    if mode == "lane":
+        monkeypatch.setenv("RT_TRAVERSAL", "lane")
+        monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    base = scenes["original"]
+    matid = base.matid.copy()
+    light_mat = int(matid[base.light_tri[0]])
+    matid[5] = light_mat  # a wall triangle becomes a third light
+    sc = orc.Scene.from_arrays(base.pos, None, matid, base.materials)
+    assert sc.n_light == 3
+    g = build(rt, sc)
+    ot = orc.Octree(sc, 16, 10)
+    kw = dict(fov=0.6, width=40, height=48, spt=spt, render_type="phong", shading="flat", **CAMERAS["original"])
+    ref, _, _, ost = orc.render(sc, ot, orc.make_cfg(rng_mode=orc.RNG_COUNTER, **kw), want_hits=False)
+    img, st = g.render(rt.make_render_config(**kw))
+    assert st.shadow_rays == ost.shadow_rays and st.rays == ost.search_calls
+    assert np.abs(img - ref).max() <= 1.0 / 255.0
+
+
 def test_large_tree_frame_properties(rt, monkeypatch):
     """The 1,310,754-triangle scene at a size no CPU check finishes quickly (1920x1080, true aspect): the frame must not
     depend on where the tree was built or on which traversal form walks it."""
