@@ -138,12 +138,14 @@ def main():
         rays += st.rays
         shade_ms += st.ms_shade
         closest_ms += st.ms_closest
-        shade_launches += st.launches_shade
+        # per-kernel times come from HIP events around the first 64 launches of each class in a call; the ray
+        # counts used for kernel rates are those of exactly these launches
+        shade_launches += min(st.launches_shade, 64)
         shadow_ms += st.ms_shadow
-        shadow_launches += st.launches_shadow
-        closest_launches += st.launches_closest
-        shadow_rays += st.shadow_rays
-        closest_rays += st.primary_rays + st.secondary_rays
+        shadow_launches += min(st.launches_shadow, 64)
+        closest_launches += min(st.launches_closest, 64)
+        shadow_rays += st.timed_shadow_rays
+        closest_rays += st.timed_closest_rays
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -165,6 +165,9 @@ typedef struct rt_render_stats {
     uint32_t levels;              /* recursion levels that had work */
     float ms_closest, ms_shadow, ms_shade, ms_total;  /* device time by kernel class (HIP events) */
     uint32_t launches_closest, launches_shadow, launches_shade;
+    /* The events cover at most the first 64 launches of each class per call; these are the rays of exactly the timed
+     * launches, so that rays / ms is a kernel rate also for frames with more launches (many samples per pixel). */
+    uint64_t timed_closest_rays, timed_shadow_rays;
 } rt_render_stats;
 
 /* Renderer::RenderScene's hot loop (src/Renderer/renderer.cc:37-52) on the device: primary rays

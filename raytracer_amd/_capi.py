@@ -54,7 +54,8 @@ class RenderStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("rays", C.c_uint64), ("levels", C.c_uint32),
                 ("ms_closest", C.c_float), ("ms_shadow", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
-                ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32)]
+                ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32),
+                ("timed_closest_rays", C.c_uint64), ("timed_shadow_rays", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

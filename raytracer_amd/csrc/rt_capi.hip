@@ -1003,6 +1003,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     if (c->samples_per_pixel > 1) { HIP_TRY(a->d_accum.reserve((size_t)n0 * 3)); }
 
     rt_render_stats st{};
+    uint64_t valid_pixels = 0;  // of this call's bands, per sample
+    for (int b = c->band_rank; b < (c->height + 7) / 8; b += c->band_world) valid_pixels += (uint64_t)std::min(8, c->height - b * 8) * (uint64_t)c->width;
     int n_timed_closest = 0, n_timed_shade = 0, n_timed_shadow = 0;
     hipEvent_t* ev_total = a->ev;
     hipEvent_t* ev_closest = a->ev + 2;
@@ -1032,6 +1034,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             st.launches_closest++;
             if (L == 0) st.primary_rays += 0;  // counted below from the valid pixel count
             else st.secondary_rays += n;
+            if (timed_c) st.timed_closest_rays += L == 0 ? valid_pixels : n;
             levels = L + 1;
             // Camera rays mostly hit something, so for level 0 the hit count stays on the device: the any-hit and
             // shading passes are launched for the level's ray count (an upper bound; surplus blocks leave at once)
@@ -1055,9 +1058,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const dim3 grid_s((n_work + 255) / 256);
             const uint32_t words = (uint32_t)((std::max(c->samples_per_triangle, 1) + 31) / 32);
             const bool lit = c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG;
+            bool timed_a = false;
             if (lit && a->n_lights > 0 && c->samples_per_triangle > 0) {
                 HIP_TRY(lv.vis.reserve((size_t)n_work * a->n_lights * words));
-                const bool timed_a = n_timed_shadow < kMaxTimed;
+                timed_a = n_timed_shadow < kMaxTimed;
                 if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
                 // lanes per hit in the any-hit pass: the (light, sample) pairs of a hit, samples padded to a power of
                 // two per light, side by side in at most 64 lanes
@@ -1089,7 +1093,9 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             }
             st.launches_shade++;
             if (int rc = read_counters(a, L, stream)) return rc;
-            st.shadow_rays += (uint64_t)a->h_counters[CNT_SHADOW_LO] | ((uint64_t)a->h_counters[CNT_SHADOW_HI] << 32);
+            const uint64_t level_shadow = (uint64_t)a->h_counters[CNT_SHADOW_LO] | ((uint64_t)a->h_counters[CNT_SHADOW_HI] << 32);
+            st.shadow_rays += level_shadow;
+            if (timed_a) st.timed_shadow_rays += level_shadow;
             n = a->h_counters[CNT_NEXT];
             if (n > next_cap) return fail(RT_ERR_HIP, "internal: recursion queue overflow (%u > %u)", n, next_cap);
         }
