@@ -43,19 +43,22 @@ class BandGather:
         self.height, self.width, self.rank, self.world, self.dist = height, width, rank, world, dist
         self.bands_pad = padded_bands(height, world)
         self.row_floats = BAND_ROWS * width * 3
-        per_rank = self.bands_pad // world
+        self.per_rank = self.bands_pad // world
+        self.recv = None
         self.parts = None
         if dist is not None and rank == 0:
-            self.parts = [torch.empty((per_rank, self.row_floats), dtype=torch.float32, device=device) for _ in range(world)]
+            # one receive buffer [rank][band of that rank][band bytes]; the gather list is its per-rank views
+            self.recv = torch.empty((world, self.per_rank, self.row_floats), dtype=torch.float32, device=device)
+            self.parts = list(self.recv.unbind(0))
 
     def __call__(self, frame):
         """frame: alloc_frame(...) tensor holding this rank's bands.  On return rank 0's frame is complete."""
         if self.dist is None:
             return frame
-        fv = frame.view(self.bands_pad, self.row_floats)
-        mine = fv[self.rank::self.world].contiguous()
+        # band b = k * world + r  ->  view [k][r][band bytes]
+        fv = frame.view(self.per_rank, self.world, self.row_floats)
+        mine = fv[:, self.rank].contiguous()
         self.dist.gather(mine, self.parts, dst=0)
         if self.rank == 0:
-            for r in range(1, self.world):
-                fv[r::self.world] = self.parts[r]
+            fv.copy_(self.recv.permute(1, 0, 2))  # one interleaving copy (rank 0's own bands are rewritten with themselves)
         return frame
