@@ -66,6 +66,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line.  Native libraries (RCCL prints a version banner when a communicator is
+    # created) write to file descriptor 1 directly, so everything but the final line is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import raytracer_amd as rt
@@ -240,7 +246,8 @@ def main():
                 hits = (shadow_rays / max(shadow_launches, 1)) / (wl["spt"] * n_lights)
                 roof["algorithmic_bytes_per_launch"] = hits * (12.0 + 4.0 * n_lights * ((wl["spt"] + 31) // 32))
         out["roofline"] = roof
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
