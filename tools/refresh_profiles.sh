@@ -18,4 +18,6 @@ echo "fetch pass done"
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH > "$OUT/write.log" 2>&1
 echo "write pass done"
 cd "$ROOT"
+# the bench line of the profiled run itself: its HIP-event kernel times are the ones to compare with the stats table
+grep -o '{"metric.*' "$OUT/stats.log" > "$ROOT/gpurun_out/profiles_new/${TAG}_rocprofv3_bench_line.json" || true
 python3 tools/summarize_profiles.py "$OUT" "$ROOT/gpurun_out/profiles_new" "$TAG"
