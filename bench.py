@@ -29,19 +29,19 @@ CAM_ORIGINAL = dict(cam_pos=[278.0, 273.0, -1000.0], cam_up=[0.0, 1.0, 0.0], cam
 CAM_SPHERE = dict(cam_pos=[0.0, 1.0, 4.42], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, -1.0], max_distance=6.0)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    # the configuration the headline metric is quoted on: Cornell-Original, Blinn-Phong, 16 samples per light, 1080p
     "cornell_original_blinn_spt16_1080p": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=1920, height=1080, spp=1, spt=16, render_type="blinn_phong",
         shading="flat", cull=True, max_depth=10, cpu_rows=(0, 320)),
-    # configs[2]
+    # Cornell-Sphere (reflection + refraction), smooth shading, 4 samples per pixel, 32 samples per light
     "cornell_sphere_blinn_smooth_spp4_1080p": dict(
         scene="cornell_sphere", cam=CAM_SPHERE, width=1920, height=1080, spp=4, spt=32, render_type="blinn_phong",
         shading="smooth", cull=True, max_depth=10, cpu_rows=(540, 545)),
-    # configs[3]: 1,310,754 triangles (Cornell box + icosphere level 8), hard shadows, true aspect ratio
+    # 1,310,754 triangles (Cornell box + icosphere level 8), hard shadows, true aspect ratio
     "synthetic_ico8_phong_4k": dict(
         scene="synthetic:8", cam=CAM_ORIGINAL, width=3840, height=2160, spp=1, spt=1, render_type="phong",
         shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160)),
-    # configs[4]: fuzzysampling + 32 light samples, 4K
+    # fuzzysampling (64 samples per pixel) + 32 samples per light, 4K
     "cornell_original_blinn_spp64_spt32_4k": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong",
         shading="flat", cull=True, max_depth=10, cpu_rows=(1080, 1082)),
