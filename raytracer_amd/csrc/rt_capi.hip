@@ -1039,9 +1039,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             // Camera rays mostly hit something, so for level 0 the hit count stays on the device: the any-hit and
             // shading passes are launched for the level's ray count (an upper bound; surplus blocks leave at once)
             // and the level costs one host synchronisation (for the size of the next level) instead of two.
-            // Deeper levels often hit nothing at all; there the count is read first.
+            // Deeper levels often hit nothing at all; there the count is read first -- unless the level is so small
+            // that launching for all of its rays costs less than the synchronisation.
             uint32_t n_work = n;
-            if (L > 0) {
+            if (L > 0 && ((uint64_t)n * (uint64_t)std::max(c->samples_per_triangle, 1)) > (1ull << 24)) {
                 if (int rc = read_counters(a, L, stream)) return rc;
                 n_work = a->h_counters[CNT_WORK];
                 if (n_work == 0) break;
