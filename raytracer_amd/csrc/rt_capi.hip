@@ -1021,10 +1021,11 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             HIP_TRY(lv.reserve(n, L > 0));
             lv.n = n;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
-            const dim3 grid((n + 255) / 256);
+            const bool closest_lanes = lane_mode(a, L == 0);
+            const dim3 block_c(closest_lanes ? 256 : 1024), grid_c((n + block_c.x - 1) / block_c.x);
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            RT_LAUNCH2(k_closest, F.cull != 0, lane_mode(a, L == 0), grid, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+            RT_LAUNCH2(k_closest, F.cull != 0, closest_lanes, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
                        lv.work.p, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
@@ -1177,7 +1178,9 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
         d_tri = (int32_t*)(a->d_io.p + npix * 4);
     }
     const dim3 block(256), grid((n0 + 255) / 256);
-    RT_LAUNCH2(k_closest, F.cull != 0, lane_mode(a, true), grid, block, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
+    const bool closest_lanes = lane_mode(a, true);
+    const dim3 block_c(closest_lanes ? 256 : 1024), grid_c((n0 + block_c.x - 1) / block_c.x);
+    RT_LAUNCH2(k_closest, F.cull != 0, closest_lanes, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
                lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);

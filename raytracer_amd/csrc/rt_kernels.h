@@ -158,15 +158,16 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
     return base + (uint32_t)__builtin_popcountll(below);
 }
 
-// The same for a whole 256-thread block with ONE atomic per block: a single counter word sustains only some tens of
-// atomics per microsecond, and a 1080p level has 32k waves.  Every thread of the block must call it (once per kernel).
-// `weight` is summed over the block into the 64-bit counter at `sum64` (also one atomic per block).
+// The same for a whole block (up to 1024 threads) with ONE atomic per block: a single counter word sustains only some
+// tens of atomics per microsecond, and a 1080p level has 32k waves.  Every thread of the block must call it (once per
+// kernel).  `weight` is summed over the block into the 64-bit counter at `sum64` (also one atomic per block).
+constexpr int kMaxBlockWaves = 16;
 __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, uint32_t weight, uint32_t* sum64) {
-    __shared__ uint32_t s_count[4];
-    __shared__ uint32_t s_weight[4];
+    __shared__ uint32_t s_count[kMaxBlockWaves];
+    __shared__ uint32_t s_weight[kMaxBlockWaves];
     __shared__ uint32_t s_base;
     const uint64_t m = ballot64(want);
-    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     uint32_t w = weight;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
@@ -176,14 +177,17 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+        uint32_t total = 0, wsum = 0;
+        for (uint32_t k = 0; k < n_waves; ++k) {
+            total += s_count[k];
+            wsum += s_weight[k];
+        }
         s_base = total ? atomicAdd(counter, total) : 0u;
-        const uint32_t wsum = s_weight[0] + s_weight[1] + s_weight[2] + s_weight[3];
         if (wsum) atomicAdd((unsigned long long*)sum64, (unsigned long long)wsum);
     }
     __syncthreads();
     uint32_t at = s_base;
-    for (uint32_t w = 0; w < wave; ++w) at += s_count[w];
+    for (uint32_t k = 0; k < wave; ++k) at += s_count[k];
     const uint64_t below = m & ((1ull << lane) - 1ull);
     return at + (uint32_t)__builtin_popcountll(below);
 }
@@ -256,8 +260,10 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 }
 
 // Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
+// Launched with 1024-thread blocks when the wave walks together (fewer compaction atomics), with 256-thread blocks for
+// the per-lane traversal (its LDS stack is sized for 256 threads).
 template <bool CULL, bool LANE>
-__global__ void __launch_bounds__(256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(LANE ? 256 : 1024) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
     const uint32_t i = xcd_block() * blockDim.x + threadIdx.x;
