@@ -179,6 +179,26 @@ bool lane_mode(const rt_ads* a, bool coherent_primary) {
     return !coherent_primary;
 }
 
+// Threads per block of k_closest.  Its hit compaction costs one atomic per block and the whole block waits for its
+// slowest wave there: big blocks pay off where waves take similar, short times (small trees), not on big trees where
+// a wave over a finely tessellated region runs many times longer than its neighbours.
+uint32_t closest_block(const rt_ads* a, bool lanes) { return (!lanes && a->n_slots < 32768) ? 1024u : 256u; }
+
+template <class... Args>
+void launch_closest(bool cull, bool lanes, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+    const bool big = block.x > 256;
+    if (lanes) {
+        if (cull) hipLaunchKernelGGL((k_closest<true, true, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, true, false>), grid, block, 0, stream, args...);
+    } else if (big) {
+        if (cull) hipLaunchKernelGGL((k_closest<true, false, true>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, false, true>), grid, block, 0, stream, args...);
+    } else {
+        if (cull) hipLaunchKernelGGL((k_closest<true, false, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, false, false>), grid, block, 0, stream, args...);
+    }
+}
+
 int use_device(const rt_ads* a) {
     HIP_TRY(hipSetDevice(a->device));
     return RT_OK;
@@ -1022,10 +1042,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             lv.n = n;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
             const bool closest_lanes = lane_mode(a, L == 0);
-            const dim3 block_c(closest_lanes ? 256 : 1024), grid_c((n + block_c.x - 1) / block_c.x);
+            const dim3 block_c(closest_block(a, closest_lanes)), grid_c((n + block_c.x - 1) / block_c.x);
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            RT_LAUNCH2(k_closest, F.cull != 0, closest_lanes, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+            launch_closest(F.cull != 0, closest_lanes, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
                        lv.work.p, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
@@ -1179,8 +1199,8 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     }
     const dim3 block(256), grid((n0 + 255) / 256);
     const bool closest_lanes = lane_mode(a, true);
-    const dim3 block_c(closest_lanes ? 256 : 1024), grid_c((n0 + block_c.x - 1) / block_c.x);
-    RT_LAUNCH2(k_closest, F.cull != 0, closest_lanes, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
+    const dim3 block_c(closest_block(a, closest_lanes)), grid_c((n0 + block_c.x - 1) / block_c.x);
+    launch_closest(F.cull != 0, closest_lanes, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
                lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);

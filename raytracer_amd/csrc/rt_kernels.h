@@ -260,10 +260,10 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 }
 
 // Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
-// Launched with 1024-thread blocks when the wave walks together (fewer compaction atomics), with 256-thread blocks for
-// the per-lane traversal (its LDS stack is sized for 256 threads).
-template <bool CULL, bool LANE>
-__global__ void __launch_bounds__(LANE ? 256 : 1024) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+// BIG: launched with 1024-thread blocks (a quarter of the compaction atomics; only for the wave-together form on small
+// trees, see closest_block()); otherwise 256-thread blocks (the per-lane LDS stack is sized for 256 threads).
+template <bool CULL, bool LANE, bool BIG>
+__global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
     const uint32_t i = xcd_block() * blockDim.x + threadIdx.x;
