@@ -294,6 +294,43 @@ def test_device_builder_equals_host_builder(rt, scenes, scene, mb, md):
     assert not d2 and n2.tobytes() == h_nodes.tobytes() and s2.tobytes() == h_slots.tobytes() and r2 == root and m2 == max_stack
 
 
+def _rng_free_kats():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "ref_kats.json")) as f:
+        kats = json.load(f)
+    return {k: v for k, v in kats.items() if v["spec"]["render_type"] in ("distance", "diffusion") and v["spec"]["ads"] == "octree"}
+
+
+@pytest.mark.parametrize("name", sorted(_rng_free_kats()))
+def test_reference_binary_known_answers(rt, scenes, name):
+    """The render types that draw no random numbers, straight against what the unmodified reference binary produced
+    (tests/golden/ref_kats.json): the md5 of the PPM file it wrote and its "Search method call count" -- camera rays plus
+    every reflection / refraction ray of the recursion -- and the tree shape it printed."""
+    import hashlib
+    k = _rng_free_kats()[name]
+    sp = k["spec"]
+    if sp["scene"] == "synthetic":
+        s = synthetic_scene(sp["levels"])
+        pos, nrm, matid, mats, cam = s.pos, None, s.matid, s.materials, CAMERAS["original"]
+    else:
+        sc = scenes[sp["scene"]]
+        pos, nrm, matid, mats, cam = sc.pos, (sc.norm if sc.has_normals else None), sc.matid, sc.materials, CAMERAS[sp["scene"]]
+    g = rt.GpuOctree({"max_triangles_per_BB": sp.get("tri_per_bb", 16), "max_depth": sp.get("ads_depth", 10)})
+    g.Build(pos)
+    g.set_shading(nrm, matid, mats)
+    img, st = g.render(rt.make_render_config(fov=0.6, width=sp["w"], height=sp["h"], spp=sp.get("spp", 1), spt=sp.get("spt", 1),
+                                             render_type=sp["render_type"], shading=sp["shading"], cull=sp.get("cull", True), **cam))
+    # the P3 text of Renderer::save_image (renderer.cc:381-390, color.h:12-15)
+    q = (255.999 * img.astype(np.float64)).astype(np.int64).reshape(-1, 3)
+    text = f"P3\n{sp['w']} {sp['h']}\n255\n" + "".join(f"{r} {gg} {b}\n" for r, gg, b in q.tolist())
+    assert hashlib.md5(text.encode()).hexdigest() == k["ppm_md5"]
+    assert st.rays == k["search_calls"]
+    ts = g.tree_stats()
+    assert (ts["nodes"], ts["leaves"], ts["max_depth"], ts["max_triangles_in_leaf"]) == (k["nodes"], k["leaves"], k["max_depth"], k["max_tris_in_leaf"])
+
+
 def test_render_is_partition_independent(rt, scenes):
     """Rendering the image in interleaved bands (as 2 or 3 ranks would) gives the same pixels as one call."""
     sc = scenes["original"]
