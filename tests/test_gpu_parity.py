@@ -176,6 +176,44 @@ def test_empty_and_tiny_scenes(rt, orc, scenes):
     assert np.array_equal(g.Search(np.concatenate([o[0], d[0]])), np.arange(5))
 
 
+@pytest.mark.parametrize("mode", ["auto", "wave", "lane"])
+@pytest.mark.parametrize("scene", ["original", "sphere"])
+def test_degenerate_rays_and_ragged_batches(rt, orc, scenes, monkeypatch, scene, mode):
+    """Zero, denormal, huge, infinite and NaN ray components take the inf / NaN branches of the slab and triangle tests;
+    batch sizes 0, 1, 63, 65 and 257 leave waves and blocks partly empty.  Results must still equal the oracle's bits,
+    in every traversal form."""
+    if mode != "auto":
+        monkeypatch.setenv("RT_TRAVERSAL", mode)
+        monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    sc = scenes[scene]
+    g = build(rt, sc)
+    ot = orc.Octree(sc, 16, 10)
+    o, d = random_rays(sc, 4096, 99)
+    special = np.array([0.0, -0.0, 1e-40, -1e-40, 1e30, -1e30, np.inf, -np.inf, np.nan, 1.0], np.float32)
+    rs = np.random.RandomState(8)
+    for i in range(0, 2048, 2):
+        d[i, rs.randint(3)] = special[rs.randint(len(special))]
+    for i in range(1, 1024, 4):
+        o[i, rs.randint(3)] = special[rs.randint(len(special))]
+    d[7] = [0.0, 0.0, 0.0]
+    d[9] = [np.nan, np.nan, np.nan]
+    o[11] = sc.pos[0, 0]           # origin on a vertex ...
+    d[11] = sc.pos[0, 1] - sc.pos[0, 0]  # ... direction along an edge
+    with np.errstate(all="ignore"):
+        for cull in (True, False):
+            t_ref, tri_ref = ot.trace_closest(o, d, cull)
+            t, tri = g.trace_closest(o, d, cull)
+            assert np.array_equal(tri, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+            L = (o + d * 0.75).astype(np.float32)
+            assert np.array_equal(ot.trace_any(o, L, cull), g.trace_any(o, L, cull))
+        for n in (0, 1, 63, 65, 257):
+            t_ref, tri_ref = ot.trace_closest(o[:n], d[:n], True)
+            t, tri = g.trace_closest(o[:n], d[:n], True)
+            assert t.shape == (n,) and np.array_equal(tri, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+            assert np.array_equal(ot.trace_any(o[:n], d[:n], True), g.trace_any(o[:n], d[:n], True))
+    assert len(g.search_batch(np.zeros((0, 6), np.float32))) == 0
+
+
 def test_tree_stats_match_reference(rt, scenes):
     g = build(rt, scenes["sphere"])
     st = g.tree_stats()
