@@ -205,6 +205,21 @@ def main():
             flops_closest = 3 + 18 * b_cl + 52 * t_cl
             out["reference_work_per_ray"] = {"any_hit": {"B": b_any, "T": t_any, "flops": flops_any},
                                              "closest_hit": {"B": b_cl, "T": t_cl, "flops": flops_closest}}
+            # The unmodified reference binary itself (built from the reference's sources where they exist; the binary
+            # travels with the repository), on the same scene and settings at a reduced image size, one sample per
+            # pixel: about 5 M rays.  The time is the whole process (scene load, Build, frame, PPM write).
+            import ref_runner
+            if ref_runner.available() and not wl["scene"].startswith("synthetic:"):
+                scale = max(1, int(round(((rays / args.steps / wl["spp"]) / 5e6) ** 0.5)))
+                rw, rh = max(8, W // scale), max(8, H // scale)
+                rr = ref_runner.run(scene.pos, scene.norm, scene.matid, scene.materials, wl["cam"]["cam_pos"], wl["cam"]["cam_up"],
+                                    wl["cam"]["cam_dir"], 0.6, rw, rh, spp=1, spt=wl["spt"], render_type=wl["render_type"],
+                                    shading=wl["shading"], cull=wl["cull"], max_depth=wl["max_depth"],
+                                    max_distance=wl["cam"]["max_distance"])
+                out["cpu_baseline_reference"] = {
+                    "value": rr["search_calls"] / rr["wall_s"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                    "sample": f"oracle/_ref/raytracer_ref (-O2, glibc rand) on the same scene and settings at {rw}x{rh}, 1 sample "
+                              f"per pixel: {rr['search_calls']} Search calls in {rr['wall_s']:.1f} s (whole process)"}
         if world == 1:
             # the same frame with the framebuffer handed back in host memory (device -> host copy inside the call);
             # reported beside `value`, never as it

@@ -59,6 +59,29 @@ def test_reference_image_and_counters(orc, scenes, name):
         assert abs(ts["avg_tris_in_leaf"] - k["avg_tris_in_leaf"]) < 1e-3
 
 
+@pytest.mark.parametrize("name", ["K2", "K3", "K4", "K5", "K11"])
+def test_reference_binary_on_scene_arrays(scenes, name):
+    """oracle/ref_runner.py feeds the reference binary a scene written from the committed arrays (not the reference's
+    own resource files, which do not travel).  It must print and write what it did for its own files: same PPM md5,
+    same counters -- so timing it on another host measures the reference on the real scene."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+    import ref_runner
+    if not ref_runner.available():
+        pytest.skip("oracle/_ref/raytracer_ref has not been built")
+    k = KATS[name]
+    sp = k["spec"]
+    sc = scenes[sp["scene"]]
+    cam = CAMERAS[sp["scene"]]
+    out = ref_runner.run(sc.pos, sc.norm if sc.has_normals else None, sc.matid, sc.materials, cam["cam_pos"], cam["cam_up"],
+                         cam["cam_dir"], 0.6, sp["w"], sp["h"], spp=sp.get("spp", 1), spt=sp.get("spt", 1),
+                         render_type=sp["render_type"], shading=sp["shading"], cull=sp.get("cull", True),
+                         max_distance=cam["max_distance"], tri_per_bb=sp.get("tri_per_bb", 16), ads_depth=sp.get("ads_depth", 10))
+    assert out["ppm_md5"] == k["ppm_md5"]
+    assert out["search_calls"] == k["search_calls"] and out["tri_tests"] == k["tri_tests"]
+    assert out["nodes"] == k["nodes"] and out["leaves"] == k["leaves"]
+
+
 def test_published_tree_shape(orc, scenes):
     """report/report.tex:178-186 of the reference: 1,584 nodes / 1,300 leaves / 5.22 / 34 / 7.03."""
     ts = orc.Octree(scenes["sphere"], 16, 10).stats()
