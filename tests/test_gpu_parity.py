@@ -369,6 +369,47 @@ def test_reference_binary_known_answers(rt, scenes, name):
     assert (ts["nodes"], ts["leaves"], ts["max_depth"], ts["max_triangles_in_leaf"]) == (k["nodes"], k["leaves"], k["max_depth"], k["max_tris_in_leaf"])
 
 
+LIVE_CASES = [
+    # scene, render_type, shading, cull, w, h, camera position, direction, fov, octree (per box, depth)
+    ("original", "distance", "flat", True, 90, 120, [100.0, 400.0, -700.0], [0.2, -0.15, 1.0], 0.8, (16, 10)),
+    ("original", "diffusion", "flat", False, 75, 75, [278.0, 273.0, -400.0], [0.0, 0.0, 1.0], 1.1, (6, 4)),
+    ("sphere", "diffusion", "smooth", True, 64, 100, [0.3, 1.2, 3.9], [-0.05, -0.1, -1.0], 0.7, (16, 10)),
+    ("sphere", "distance", "flat", False, 101, 67, [-0.4, 0.8, 4.2], [0.1, 0.05, -1.0], 0.5, (3, 12)),
+]
+
+
+@pytest.mark.parametrize("case", LIVE_CASES, ids=[f"{c[0]}_{c[1]}_{i}" for i, c in enumerate(LIVE_CASES)])
+def test_against_the_reference_binary_run_live(rt, scenes, case):
+    """Configurations that are in no fixture: the reference binary (oracle/_ref/raytracer_ref, travelling with the
+    repository) renders them on this host, the device path renders them too, and the PPM files must be identical byte
+    for byte, like the Search call counts (camera + reflection + refraction rays) and the tree shape."""
+    import hashlib
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_runner
+    if not ref_runner.available():
+        pytest.skip("oracle/_ref/raytracer_ref has not been built")
+    scene, rtype, shading, cull, w, h, cpos, cdir, fov, (mb, md) = case
+    sc = scenes[scene]
+    nrm = sc.norm if sc.has_normals else None
+    maxd = CAMERAS[scene]["max_distance"]
+    ref = ref_runner.run(sc.pos, nrm, sc.matid, sc.materials, cpos, [0.0, 1.0, 0.0], cdir, fov, w, h, render_type=rtype,
+                         shading=shading, cull=cull, max_distance=maxd, tri_per_bb=mb, ads_depth=md)
+    g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+    g.Build(sc.pos)
+    g.set_shading(nrm, sc.matid, sc.materials)
+    img, st = g.render(rt.make_render_config(cam_pos=cpos, cam_up=[0.0, 1.0, 0.0], cam_dir=cdir, fov=fov, width=w, height=h,
+                                             render_type=rtype, shading=shading, cull=cull, max_distance=maxd))
+    q = (255.999 * img.astype(np.float64)).astype(np.int64).reshape(-1, 3)
+    text = f"P3\n{w} {h}\n255\n" + "".join(f"{r} {gg} {b}\n" for r, gg, b in q.tolist())
+    assert hashlib.md5(text.encode()).hexdigest() == ref["ppm_md5"]
+    assert st.rays == ref["search_calls"]
+    ts = g.tree_stats()
+    assert (ts["nodes"], ts["leaves"]) == (ref["nodes"], ref["leaves"])
+
+
 @pytest.mark.parametrize("name", ["K5", "K9"])
 def test_area_light_images_match_the_reference_statistically(rt, orc, scenes, name):
     """With area lights the reference consumes one global rand() stream in pixel order, which no parallel renderer can
