@@ -410,6 +410,46 @@ def test_against_the_reference_binary_run_live(rt, scenes, case):
     assert (ts["nodes"], ts["leaves"]) == (ref["nodes"], ref["leaves"])
 
 
+@pytest.mark.parametrize("seed,n_tri,mb,md", [(1, 300, 16, 10), (2, 2000, 8, 6), (3, 5000, 16, 10), (4, 64, 2, 8)])
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_random_triangle_soups_against_the_reference_binary(rt, scenes, seed, n_tri, mb, md, builder):
+    """Geometry nobody tuned for: random triangles of very different sizes, slivers, exact duplicates and triangles
+    that share vertices, with random materials (so reflection and refraction rays occur).  The reference binary builds
+    its octree and renders the diffusion image on this host; both builders of the device path must give the same tree
+    shape, the same Search call count and the same PPM bytes."""
+    import hashlib
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_runner
+    if not ref_runner.available():
+        pytest.skip("oracle/_ref/raytracer_ref has not been built")
+    rs = np.random.RandomState(seed)
+    centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+    size = np.exp(rs.uniform(np.log(0.02), np.log(4.0), (n_tri, 1, 1)))
+    pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+    pos[::17, 2] = pos[::17, 1] + (pos[::17, 1] - pos[::17, 0]) * 1e-3 + 1e-4   # slivers
+    pos[5::40] = pos[4::40][: len(pos[5::40])]                                   # exact duplicates
+    pos[7::23, 0] = pos[6::23, 0][: len(pos[7::23])]                             # shared vertices
+    mats = scenes["sphere"].materials
+    matid = rs.randint(0, mats.shape[0], n_tri).astype(np.int32)
+    cpos, cdir, fov, w, h = [0.5, 0.3, -14.0], [0.0, 0.0, 1.0], 0.9, 96, 128
+    ref = ref_runner.run(pos, None, matid, mats, cpos, [0.0, 1.0, 0.0], cdir, fov, w, h, render_type="diffusion", shading="flat",
+                         cull=False, max_distance=40.0, tri_per_bb=mb, ads_depth=md, max_depth=4)
+    g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md, "builder": builder})
+    g.Build(pos)
+    g.set_shading(None, matid, mats)
+    img, st = g.render(rt.make_render_config(cam_pos=cpos, cam_up=[0.0, 1.0, 0.0], cam_dir=cdir, fov=fov, width=w, height=h,
+                                             render_type="diffusion", shading="flat", cull=False, max_distance=40.0, max_depth=4))
+    ts = g.tree_stats()
+    assert (ts["nodes"], ts["leaves"]) == (ref["nodes"], ref["leaves"])
+    assert st.rays == ref["search_calls"]
+    q = (255.999 * img.astype(np.float64)).astype(np.int64).reshape(-1, 3)
+    text = f"P3\n{w} {h}\n255\n" + "".join(f"{r} {gg} {b}\n" for r, gg, b in q.tolist())
+    assert hashlib.md5(text.encode()).hexdigest() == ref["ppm_md5"]
+
+
 @pytest.mark.parametrize("name", ["K5", "K9"])
 def test_area_light_images_match_the_reference_statistically(rt, orc, scenes, name):
     """With area lights the reference consumes one global rand() stream in pixel order, which no parallel renderer can
