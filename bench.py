@@ -116,16 +116,28 @@ def main():
     cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
 
     from raytracer_amd import distributed as rd
-    frame = rd.alloc_frame(H, W, world, "cuda")
+    # Two frame buffers: while the bands of one frame travel to rank 0 (RCCL, on its own stream), the next frame is
+    # rendered into the other buffer.  RT_BENCH_SYNC_GATHER=1 completes every gather before the next frame starts.
+    frames = [rd.alloc_frame(H, W, world, "cuda") for _ in range(2)]
+    frame = frames[0]
     stream = torch.cuda.current_stream().cuda_stream
-    gather = rd.BandGather(H, W, rank, world, "cuda", dist)
+    gathers = [rd.BandGather(H, W, rank, world, "cuda", dist) for _ in range(2)]
+    overlap = dist is not None and os.environ.get("RT_BENCH_SYNC_GATHER") != "1"
+    step_no = [0]
 
     def step():
-        _, st = ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
-        gather(frame)  # framebuffer bands -> rank 0 (RCCL); no-op for one rank
+        k = step_no[0] & 1
+        step_no[0] += 1
+        gathers[k].finish()  # this buffer's previous frame must have arrived before it is overwritten
+        _, st = ads.render(cfg, out_ptr=frames[k].data_ptr(), stream=stream)
+        gathers[k].start(frames[k])  # framebuffer bands -> rank 0; no-op for one rank
+        if not overlap:
+            gathers[k].finish()
         return st
 
     def fence():
+        for g_ in gathers:
+            g_.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

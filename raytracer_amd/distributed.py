@@ -51,14 +51,38 @@ class BandGather:
             self.recv = torch.empty((world, self.per_rank, self.row_floats), dtype=torch.float32, device=device)
             self.parts = list(self.recv.unbind(0))
 
-    def __call__(self, frame):
-        """frame: alloc_frame(...) tensor holding this rank's bands.  On return rank 0's frame is complete."""
+        self.mine = None
+        if dist is not None:
+            self.mine = torch.empty((self.per_rank, self.row_floats), dtype=torch.float32, device=device)
+        self._work = None
+        self._frame = None
+
+    def start(self, frame):
+        """Begins the gather of `frame` (alloc_frame(...) tensor holding this rank's bands) without waiting for it: the
+        collective runs on the backend's own stream, so the caller may render the next frame -- into ANOTHER buffer, with
+        ANOTHER BandGather -- meanwhile.  finish() completes it."""
         if self.dist is None:
-            return frame
+            return
+        assert self._work is None, "finish() the previous gather first"
         # band b = k * world + r  ->  view [k][r][band bytes]
         fv = frame.view(self.per_rank, self.world, self.row_floats)
-        mine = fv[:, self.rank].contiguous()
-        self.dist.gather(mine, self.parts, dst=0)
+        self.mine.copy_(fv[:, self.rank])
+        self._work = self.dist.gather(self.mine, self.parts, dst=0, async_op=True)
+        self._frame = frame
+
+    def finish(self):
+        """Waits for the gather begun by start(); on return rank 0's frame is complete (on the current stream)."""
+        if self._work is None:
+            return
+        self._work.wait()
         if self.rank == 0:
+            fv = self._frame.view(self.per_rank, self.world, self.row_floats)
             fv.copy_(self.recv.permute(1, 0, 2))  # one interleaving copy (rank 0's own bands are rewritten with themselves)
+        self._work = None
+        self._frame = None
+
+    def __call__(self, frame):
+        """frame: alloc_frame(...) tensor holding this rank's bands.  On return rank 0's frame is complete."""
+        self.start(frame)
+        self.finish()
         return frame
