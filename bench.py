@@ -7,7 +7,8 @@ One step = one frame of the workload rendered through the C ABI (rt_render): pri
 hits, area-light shadow rays (any-hit), reflection / refraction levels, with the scene resident in
 HBM.  For N > 1 (launched with torch.distributed.run, one rank per GPU) the image is cut into bands
 of 8 pixel rows dealt round-robin to the ranks, the scene is replicated, and the bands are gathered
-to rank 0 over RCCL inside the timed region; the total work is fixed ("strong" scaling).
+to rank 0 over RCCL inside the timed region (the gather of a frame overlaps the rendering of the next
+one; all of them are complete before the clock stops); the total work is fixed ("strong" scaling).
 
 Prints ONE JSON line on rank 0.  metric = Mrays/s, one ray = one Search-equivalent query of the
 reference (primary, secondary or shadow).  `roofline` prices the dominant kernel (k_shadow: the
