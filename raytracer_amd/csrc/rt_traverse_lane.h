@@ -34,6 +34,15 @@ constexpr int kLaneBlock = 256;      // threads per block of the kernels that us
 #define RT_LANE_A_DEN 2
 #endif
 
+// A lane may hold a second leaf before the leaf phase starts (it keeps descending meanwhile).  Closest-hit rays gain
+// from it (fewer, fuller rounds); any-hit rays do not: their first leaf often already decides them.
+#ifndef RT_LANE_TWO_LEAVES_CLOSEST
+#define RT_LANE_TWO_LEAVES_CLOSEST 1
+#endif
+#ifndef RT_LANE_TWO_LEAVES_ANY
+#define RT_LANE_TWO_LEAVES_ANY 0
+#endif
+
 struct LaneStackLds {
     uint32_t e[kLaneMaxLevels][kLaneBlock];
     uint32_t hd[kLaneBlock];  // per wave: which lane's leaf starts at each position of the current 64-pair chunk
@@ -105,7 +114,9 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
     bool active = valid;
     bool found = false;
-    uint32_t leaf_slot = 0, leaf_left = 0;
+    constexpr bool kTwo = ANY ? (RT_LANE_TWO_LEAVES_ANY != 0) : (RT_LANE_TWO_LEAVES_CLOSEST != 0);
+    uint32_t leaf_slot = 0, leaf_left = 0;    // the leaf the lane holds
+    uint32_t leaf_slot2 = 0, leaf_left2 = 0;  // a second one (kTwo)
     uint32_t cur_rec = 0, cur_pending = 0;
     int sp = 0;
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
@@ -119,11 +130,12 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
         // ---- phase A: active lanes without a leaf take descent steps.  The phase ends when they all hold a leaf
         // (or are finished), or earlier once few of them are still searching: those resume in the next round.
         for (;;) {
-            const lanemask searching = ballot64(active && leaf_left == 0);
+            const bool can_search = active && (kTwo ? leaf_left2 == 0 : leaf_left == 0);
+            const lanemask searching = ballot64(can_search);
             if (searching == 0) break;
-            const lanemask holding = ballot64(leaf_left != 0);
+            const lanemask holding = ballot64(leaf_left != 0 && !can_search);  // lanes that only wait for the leaf phase
             if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
-            if (active && leaf_left == 0) {
+            if (can_search) {
                 if (cur_pending == 0) {
                     if (sp == 0) {
                         active = false;
@@ -144,6 +156,9 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                         }
                         cur_rec = info.x;
                         cur_pending = lane_node_pass(T.nodes, cur_rec, o, inv);
+                    } else if (kTwo && leaf_left != 0) {
+                        leaf_slot2 = info.x;
+                        leaf_left2 = info.y;
                     } else {
                         leaf_slot = info.x;
                         leaf_left = info.y;
@@ -151,7 +166,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                 }
             }
         }
-        if (ballot64(active) == 0) break;
+        if (ballot64(active || leaf_left != 0) == 0) break;  // a finished lane may still hold leaves to test
         // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane owns
         // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
         // lane i of the wave tests pair base + i: it fetches the owner's ray through lane shuffles and the triangle
@@ -160,7 +175,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
         // are in slot order, so the tie rule is the lane order).
         {
             const uint32_t lane = __lane_id();
-            const uint32_t cnt = leaf_left;
+            const uint32_t cnt = leaf_left + (kTwo ? leaf_left2 : 0u);
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -183,7 +198,11 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                 const uint32_t o_excl = __shfl(excl, (int)L, 64), o_slot = __shfl(leaf_slot, (int)L, 64);
                 const f3 ro = mk(__shfl(o.x, (int)L, 64), __shfl(o.y, (int)L, 64), __shfl(o.z, (int)L, 64));
                 const f3 rd = mk(__shfl(d.x, (int)L, 64), __shfl(d.y, (int)L, 64), __shfl(d.z, (int)L, 64));
-                const uint32_t slot = o_slot + (p - o_excl);
+                uint32_t slot = o_slot + (p - o_excl);
+                if (kTwo) {  // past the owner's first leaf: its second one
+                    const uint32_t first_n = __shfl(leaf_left, (int)L, 64), o_slot2 = __shfl(leaf_slot2, (int)L, 64);
+                    if (p - o_excl >= first_n) slot = o_slot2 + (p - o_excl - first_n);
+                }
                 const bool on = pair && !((decided >> L) & 1ull);
                 const float4* r = reinterpret_cast<const float4*>(T.slots + (on ? slot : 0u));
                 const float4 r0 = r[0], r1 = r[1], r2 = r[2];
@@ -222,6 +241,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             }
             if (ANY && found) active = false;  // this ray is decided
             leaf_left = 0;
+            leaf_left2 = 0;
         }
     }
     if (ANY) h.found = ballot64(found);
