@@ -40,7 +40,7 @@ constexpr int kLaneBlock = 256;      // threads per block of the kernels that us
 #define RT_LANE_TWO_LEAVES_CLOSEST 1
 #endif
 #ifndef RT_LANE_TWO_LEAVES_ANY
-#define RT_LANE_TWO_LEAVES_ANY 0
+#define RT_LANE_TWO_LEAVES_ANY 1
 #endif
 
 struct LaneStackLds {
