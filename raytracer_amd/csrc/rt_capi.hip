@@ -103,17 +103,33 @@ struct Level {
 constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 
-// Launches KERNEL<cull, lane>(args...) for run-time cull / lane flags.
-#define RT_LAUNCH2(KERNEL, cull, lane, grid, block, stream, ...)                                          \
-    do {                                                                                                  \
-        if (cull) {                                                                                       \
-            if (lane) hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, stream, __VA_ARGS__);       \
-            else hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, stream, __VA_ARGS__);           \
-        } else {                                                                                          \
-            if (lane) hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, stream, __VA_ARGS__);      \
-            else hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, stream, __VA_ARGS__);          \
-        }                                                                                                 \
+// Launches KERNEL<cull, mode>(args...) for run-time cull / traversal mode.
+#define RT_LAUNCH2(KERNEL, cull, mode, grid, block, stream, ...)                                                    \
+    do {                                                                                                            \
+        if (cull) {                                                                                                 \
+            if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<true, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);       \
+            else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<true, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);    \
+            else hipLaunchKernelGGL((KERNEL<true, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);                \
+        } else {                                                                                                    \
+            if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<false, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);      \
+            else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<false, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);   \
+            else hipLaunchKernelGGL((KERNEL<false, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);               \
+        }                                                                                                           \
     } while (0)
+
+template <class... Args>
+void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+    if (mode == MODE_OCTET) {  // one-wave blocks
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_OCTET, 1>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_OCTET, 1>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_LANE) {  // one-wave blocks
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_LANE, 1>), grid, block, 0, stream, args...);
+    } else {
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_WAVE, 4>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_WAVE, 4>), grid, block, 0, stream, args...);
+    }
+}
 
 }  // namespace
 
@@ -121,7 +137,7 @@ struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
-    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane
+    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always eight lanes per ray
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
     uint64_t n_tri = 0;
@@ -167,37 +183,45 @@ DevOctree dev_tree(const rt_ads* a) {
     return t;
 }
 
-// Which traversal a launch uses.  Small trees are always walked by the wave together (their small-tree form bounds the
-// work by the triangle count).  Large trees: camera rays of an 8x8 pixel tile are coherent and stay wave-together;
-// shadow, secondary and caller-supplied rays are walked per lane.
-bool lane_mode(const rt_ads* a, bool coherent_primary) {
-    if (a->traversal == 1) return false;
-    if (a->traversal == 2) return a->max_stack != 0;  // a root-leaf tree has nothing to descend
+// Which traversal a launch of n_rays rays uses.  Small trees are always walked by the wave together (their small-tree
+// form bounds the work by the triangle count).  Large trees: camera rays of an 8x8 pixel tile are coherent and stay
+// wave-together; shadow, secondary and caller-supplied rays are walked per lane -- or, when the launch is too small
+// to fill the chip with one ray per lane, by eight lanes per ray.
+constexpr uint64_t kOctetMaxRays = 1u << 18;
+int traversal_mode(const rt_ads* a, bool coherent_primary, uint64_t n_rays) {
+    if (a->traversal == 1 || a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
+    if (a->traversal == 2) return MODE_LANE;
+    if (a->traversal == 3) return MODE_OCTET;
     const bool small_tree = a->use_flat && a->n_flat_tris != 0;
-    if (small_tree || a->max_stack == 0) return false;
-    if (a->n_slots < 32768) return false;
-    return !coherent_primary;
+    if (small_tree || a->n_slots < 32768 || coherent_primary) return MODE_WAVE;
+    return n_rays < kOctetMaxRays ? MODE_OCTET : MODE_LANE;
 }
 
 // Threads per block of k_closest.  Its hit compaction costs one atomic per block and the whole block waits for its
 // slowest wave there: big blocks pay off where waves take similar, short times (small trees), not on big trees where
 // a wave over a finely tessellated region runs many times longer than its neighbours.
-uint32_t closest_block(const rt_ads* a, bool lanes) { return (!lanes && a->n_slots < 32768) ? 1024u : 256u; }
+uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE && a->n_slots < 32768) ? 1024u : 256u; }
 
 template <class... Args>
-void launch_closest(bool cull, bool lanes, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
     const bool big = block.x > 256;
-    if (lanes) {
-        if (cull) hipLaunchKernelGGL((k_closest<true, true, false>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_closest<false, true, false>), grid, block, 0, stream, args...);
+    if (mode == MODE_OCTET) {
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_OCTET, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_OCTET, false>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_LANE) {
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_LANE, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_LANE, false>), grid, block, 0, stream, args...);
     } else if (big) {
-        if (cull) hipLaunchKernelGGL((k_closest<true, false, true>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_closest<false, false, true>), grid, block, 0, stream, args...);
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_WAVE, true>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_WAVE, true>), grid, block, 0, stream, args...);
     } else {
-        if (cull) hipLaunchKernelGGL((k_closest<true, false, false>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_closest<false, false, false>), grid, block, 0, stream, args...);
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_WAVE, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_WAVE, false>), grid, block, 0, stream, args...);
     }
 }
+
+// Threads a launch needs for n rays in the given mode (8 lanes per ray in the octet form).
+uint64_t mode_threads(int mode, uint64_t n_rays) { return mode == MODE_OCTET ? n_rays * 8u : n_rays; }
 
 int use_device(const rt_ads* a) {
     HIP_TRY(hipSetDevice(a->device));
@@ -656,7 +680,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (int rc = a->device_built ? device_build(a) : host_build(a)) return rc;
     if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
     a->traversal = 0;
-    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : 0);
+    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "octet") ? 3 : 0));
     if (!a->h_counters) HIP_TRY(hipHostMalloc((void**)&a->h_counters, 64 * CNT_WORDS * sizeof(uint32_t)));
     a->built = true;
     return RT_OK;
@@ -796,8 +820,9 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
     } else if (mem != RT_MEM_DEVICE) {
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
-    const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    RT_LAUNCH2(k_trace_closest, cull != 0, lane_mode(a, false), grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
+    const int mode = traversal_mode(a, false, n);
+    const dim3 block(256), grid((unsigned)((mode_threads(mode, n) + 255) / 256));
+    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -830,8 +855,9 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     } else if (mem != RT_MEM_DEVICE) {
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
-    const dim3 block(256), grid((unsigned)((n + 255) / 256));
-    RT_LAUNCH2(k_trace_any, cull != 0, lane_mode(a, false), grid, block, stream, dev_tree(a), d_p, d_l, n, d_out);
+    const int mode = traversal_mode(a, false, n);
+    const dim3 block(256), grid((unsigned)((mode_threads(mode, n) + 255) / 256));
+    RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
@@ -1041,11 +1067,11 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             HIP_TRY(lv.reserve(n, L > 0));
             lv.n = n;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
-            const bool closest_lanes = lane_mode(a, L == 0);
-            const dim3 block_c(closest_block(a, closest_lanes)), grid_c((n + block_c.x - 1) / block_c.x);
+            const int mode_c = traversal_mode(a, L == 0, n);
+            const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n) + block_c.x - 1) / block_c.x));
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            launch_closest(F.cull != 0, closest_lanes, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+            launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
                        lv.work.p, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
@@ -1091,11 +1117,14 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 30) ++pshift;
                 // Per-lane traversal gains from rays of one origin side by side (all lights of a hit in one wave);
                 // the wave-together forms measured faster with one light per pass (a narrower bundle of rays).
-                const bool lanes = lane_mode(a, false);
-                while (lanes && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
+                const int mode_a = traversal_mode(a, false, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
+                while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
-                const dim3 grid_a((uint32_t)((((uint64_t)n_work << gshift) + 255) / 256));
-                RT_LAUNCH2(k_shadow, F.cull != 0, lane_mode(a, false), grid_a, block, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
+                if (mode_a == MODE_OCTET)  // its visibility bits are or-ed into the words
+                    HIP_TRY(hipMemsetAsync(lv.vis.p, 0, (size_t)n_work * a->n_lights * words * sizeof(uint32_t), stream));
+                const dim3 block_a(mode_a == MODE_WAVE ? 256 : 64);
+                const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_work << gshift) + block_a.x - 1) / block_a.x));
+                launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
                            lv.work.p, lv.vis.p, words, pshift, gshift, cnt);
                 HIP_TRY(hipGetLastError());
                 if (timed_a) {
@@ -1198,9 +1227,9 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
         d_tri = (int32_t*)(a->d_io.p + npix * 4);
     }
     const dim3 block(256), grid((n0 + 255) / 256);
-    const bool closest_lanes = lane_mode(a, true);
-    const dim3 block_c(closest_block(a, closest_lanes)), grid_c((n0 + block_c.x - 1) / block_c.x);
-    launch_closest(F.cull != 0, closest_lanes, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
+    const int mode_c = traversal_mode(a, true, n0);
+    const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0) + block_c.x - 1) / block_c.x));
+    launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
                lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
@@ -1217,3 +1246,11 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
 }
 
 }  // extern "C"
+
+#ifdef RT_LANE_PROFILE
+extern "C" int rt_debug_lane_profile(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof z) != hipSuccess;
+}
+#endif

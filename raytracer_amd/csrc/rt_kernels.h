@@ -20,22 +20,35 @@
 
 #include "rt_traverse.h"
 #include "rt_traverse_lane.h"
+#include "rt_traverse_octet.h"
 
 namespace rt {
 
-// LANE = false: the wave walks the tree together (rt_traverse.h); LANE = true: every lane walks its own ray
-// (rt_traverse_lane.h), with its stack in the block's LDS.
-template <bool LANE>
-struct LaneStackSlot {
+// How a kernel walks the tree.  MODE_WAVE: the wave together (rt_traverse.h); MODE_LANE: every lane its own ray
+// (rt_traverse_lane.h); MODE_OCTET: eight lanes per ray (rt_traverse_octet.h) -- a thread index then names lane
+// (index & 7) of ray (index >> 3).  The per-wave stacks of the last two are in LDS; a kernel declares one slot per wave.
+enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_OCTET = 2 };
+template <int MODE>
+struct TraverseLds {
+    uint32_t unused;
+};
+template <>
+struct TraverseLds<MODE_LANE> {
     LaneStackLds s;
 };
 template <>
-struct LaneStackSlot<false> {
-    uint32_t unused;
+struct TraverseLds<MODE_OCTET> {
+    OctetStackLds s;
 };
-template <bool ANY, bool CULL, bool LANE>
-__device__ __forceinline__ void trace(const DevOctree& T, LaneStackSlot<LANE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    if constexpr (LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
+template <int MODE>
+__device__ __forceinline__ constexpr uint32_t ray_shift() { return MODE == MODE_OCTET ? 3u : 0u; }
+// the lane that writes a ray's results
+template <int MODE>
+__device__ __forceinline__ bool ray_lead(uint32_t thread) { return MODE == MODE_OCTET ? (thread & 7u) == 0u : true; }
+template <bool ANY, bool CULL, int MODE>
+__device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
+    else if constexpr (MODE == MODE_OCTET) traverse_octet<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
 }
 
@@ -194,29 +207,31 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
 
 // ---- batched queries for caller-supplied rays --------------------------------------------------------------------
 
-template <bool CULL, bool LANE>
+template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
                                                        uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
-    const uint64_t i = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
+    const uint64_t g = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
+    const uint64_t i = g >> ray_shift<MODE>();
     const bool valid = i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (valid) {
         o = mk(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
         d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     }
-    __shared__ LaneStackSlot<LANE> lds;
+    __shared__ TraverseLds<MODE> lds[4];
     HitState h;
-    trace<false, CULL, LANE>(T, lds, valid, o, d, 0.0f, h);
-    if (valid) {
+    trace<false, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
+    if (valid && ray_lead<MODE>(threadIdx.x)) {
         out_t[i] = h.t;
         out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
     }
 }
 
-template <bool CULL, bool LANE>
+template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
                                                    uint64_t n, uint8_t* __restrict__ out) {
-    const uint64_t i = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
+    const uint64_t g = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
+    const uint64_t i = g >> ray_shift<MODE>();
     const bool valid = i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
     if (valid) {
@@ -227,10 +242,10 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const f3 pl = l - p;
     const float dist = length(pl);
     const f3 d = normalize(pl);
-    __shared__ LaneStackSlot<LANE> lds;
+    __shared__ TraverseLds<MODE> lds[4];
     HitState h;
-    trace<true, CULL, LANE>(T, lds, valid, p, d, dist, h);
-    if (valid) out[i] = lane_of(h.found) ? 1 : 0;
+    trace<true, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, p, d, dist, h);
+    if (valid && ray_lead<MODE>(threadIdx.x)) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
 // ---- renderer level kernels ------------------------------------------------------------------------------------
@@ -261,21 +276,22 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 
 // Search + closest-hit loop (renderer.cc:116-142) for every node of one level.
 // BIG: launched with 1024-thread blocks (a quarter of the compaction atomics; only for the wave-together form on small
-// trees, see closest_block()); otherwise 256-thread blocks (the per-lane LDS stack is sized for 256 threads).
-template <bool CULL, bool LANE, bool BIG>
+// trees, see closest_block()); otherwise 256-thread blocks.
+template <bool CULL, int MODE, bool BIG>
 __global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
-    const uint32_t i = xcd_block() * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> ray_shift<MODE>());
+    const bool lead = ray_lead<MODE>(threadIdx.x);
     bool valid;
     f3 o, d;
     uint32_t pixel, node_id;
     load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
-    __shared__ LaneStackSlot<LANE> lds;
+    __shared__ TraverseLds<MODE> lds[BIG ? 16 : 4];
     HitState h;
-    trace<false, CULL, LANE>(S.tree, lds, valid, o, d, 0.0f, h);
-    const bool hit = valid && !(h.t == RT_INF);
-    if (valid) {
+    trace<false, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
+    const bool hit = valid && lead && !(h.t == RT_INF);
+    if (valid && lead) {
         hit_t[i] = h.t;
         hit_tri[i] = hit ? (int32_t)h.tri : -1;
         if (!hit) {  // renderer.cc:140-142: the background colour is this node's value
@@ -329,15 +345,20 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // the lights, rays of one origin side by side, and a launch has enough waves to fill the chip even for a few thousand
 // hits.  The result is one visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1
 // if not shadowed (hit j innermost); the bits of a word come from one ballot, so no two lanes write the same word.
-template <bool CULL, bool LANE>
-__global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+// MODE_OCTET (small launches): every ray has 8 lanes, the rays of a visibility word may sit in several waves, and the
+// bits are set with atomicOr into words the host has zeroed.
+// WAVES: waves per block.  The kernel has no block-level step, so the per-lane and octet forms run one-wave blocks:
+// a wave that finishes frees its slot at once instead of waiting for the slowest of four.
+template <bool CULL, int MODE, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
                                                 uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters) {
-    __shared__ LaneStackSlot<LANE> lds;
+    __shared__ TraverseLds<MODE> lds[WAVES];
     const uint32_t group = 1u << gshift;
-    const uint32_t j = (uint32_t)(((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> gshift);
-    const uint32_t sub = threadIdx.x & (group - 1u);
+    const uint64_t ray_slot = ((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> ray_shift<MODE>();
+    const uint32_t j = (uint32_t)(ray_slot >> gshift);
+    const uint32_t sub = (uint32_t)ray_slot & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
     const bool active = j < n_work;
     uint32_t i = 0;
@@ -372,7 +393,7 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
         const lanemask on_mask = ballot64(on);
         if (on_mask == 0) continue;
         // one light per pass (group == samples per light): its record is wave-uniform and comes through scalar loads
-        const uint32_t l_load = gshift <= pshift ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
+        const uint32_t l_load = (MODE != MODE_OCTET && gshift <= pshift) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
         const LightDev& L = S.lights[l_load];
         const f3 p_l = light_sample(L, pre, l, smp);
         // renderer.cc:289-290
@@ -380,11 +401,16 @@ __global__ void __launch_bounds__(256) k_shadow(SceneDev S, FrameParams F, uint3
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
         HitState h;
-        trace<true, CULL, LANE>(S.tree, lds, on, P, d_l, dist, h);
+        trace<true, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], on, P, d_l, dist, h);
         const lanemask unshadowed = on_mask & ~h.found;
         const uint32_t word = smp >> 5;
-        if (lit && writer && word < words)
-            vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
+        if constexpr (MODE == MODE_OCTET) {
+            if (lane_of(unshadowed) && ray_lead<MODE>(threadIdx.x) && word < words)
+                atomicOr(&vis[((size_t)l * words + word) * n_work + j], 1u << (smp & 31u));
+        } else {
+            if (lit && writer && word < words)
+                vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
+        }
     }
 }
 

@@ -15,8 +15,8 @@
 // passing slab tests contributes all its triangle references; equal t keeps the smaller global leaf slot.
 //
 // The per-lane stack holds one entry per tree level (record index of an internal node + the 8-bit set of its
-// octants that passed the slab test and are still to be visited), in LDS, laid out [level][thread] so that a lane's
-// bank depends only on its thread index (no conflicts whatever levels the lanes are at).
+// octants that passed the slab test and are still to be visited), in LDS, laid out [level][lane] so that a lane's
+// bank depends only on its lane index (no conflicts whatever levels the lanes are at).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,7 +26,6 @@
 namespace rt {
 
 constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
-constexpr int kLaneBlock = 256;      // threads per block of the kernels that use this traversal
 // The descent phase is left once the lanes holding a leaf outnumber RT_LANE_A_NUM / RT_LANE_A_DEN of the lanes still
 // searching (measured best on a 1.3 M-triangle scene: 1 / 2).
 #ifndef RT_LANE_A_NUM
@@ -43,9 +42,15 @@ constexpr int kLaneBlock = 256;      // threads per block of the kernels that us
 #define RT_LANE_TWO_LEAVES_ANY 1
 #endif
 
-struct LaneStackLds {
-    uint32_t e[kLaneMaxLevels][kLaneBlock];
-    uint32_t hd[kLaneBlock];  // per wave: which lane's leaf starts at each position of the current 64-pair chunk
+#ifdef RT_LANE_PROFILE
+// [ANY][k]: 0 cycles in descent, 1 cycles in leaf work, 2 descent steps, 3 lanes stepping (sum), 4 leaf chunks, 5 pairs, 6 waves, 7 rounds
+__device__ unsigned long long g_lane_prof[2][8];
+#define RT_PROF_ADD(k, v) do { if (__lane_id() == 0) atomicAdd(&g_lane_prof[ANY ? 1 : 0][k], (unsigned long long)(v)); } while (0)
+#endif
+
+struct LaneStackLds {  // of one wave
+    uint32_t e[kLaneMaxLevels][64];
+    uint32_t hd[64];  // which lane's leaf starts at each position of the current 64-pair chunk
 };
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
@@ -102,7 +107,7 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
     return pass & nonempty;
 }
 
-// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  `stk` is the block's LDS stack.
+// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  `stk` is the wave's LDS stack.
 template <bool ANY, bool CULL>
 __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& stk, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
@@ -110,7 +115,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
     h.tri = 0xffffffffu;
     h.found = 0;
     if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = __lane_id();
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
     bool active = valid;
     bool found = false;
@@ -126,7 +131,13 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
         cur_rec = T.root_info0;
         cur_pending = active ? lane_node_pass(T.nodes, cur_rec, o, inv) : 0u;
     }
+#ifdef RT_LANE_PROFILE
+    unsigned long long pa = 0, pb = 0, psteps = 0, plan = 0, pch = 0, ppairs = 0, prounds = 0;
+#endif
     for (;;) {
+#ifdef RT_LANE_PROFILE
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- phase A: active lanes without a leaf take descent steps.  The phase ends when they all hold a leaf
         // (or are finished), or earlier once few of them are still searching: those resume in the next round.
         for (;;) {
@@ -135,6 +146,9 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             if (searching == 0) break;
             const lanemask holding = ballot64(leaf_left != 0 && !can_search);  // lanes that only wait for the leaf phase
             if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
+#ifdef RT_LANE_PROFILE
+            ++psteps; plan += __builtin_popcountll(searching);
+#endif
             if (can_search) {
                 if (cur_pending == 0) {
                     if (sp == 0) {
@@ -166,6 +180,10 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                 }
             }
         }
+#ifdef RT_LANE_PROFILE
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        pa += t1 - t0;
+#endif
         if (ballot64(active || leaf_left != 0) == 0) break;  // a finished lane may still hold leaves to test
         // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane owns
         // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
@@ -179,7 +197,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            volatile uint32_t* hd = &stk.hd[tid & ~63u];
+            volatile uint32_t* hd = stk.hd;
             lanemask decided = 0;  // any-hit: owners that found an occluder earlier in this round
             for (uint32_t base = 0; base < total; base += 64) {
                 hd[lane] = 0;
@@ -242,9 +260,16 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             if (ANY && found) active = false;  // this ray is decided
             leaf_left = 0;
             leaf_left2 = 0;
+#ifdef RT_LANE_PROFILE
+            pb += __builtin_amdgcn_s_memtime() - t1;
+            pch += (total + 63) / 64; ppairs += total; ++prounds;
+#endif
         }
     }
     if (ANY) h.found = ballot64(found);
+#ifdef RT_LANE_PROFILE
+    RT_PROF_ADD(0, pa); RT_PROF_ADD(1, pb); RT_PROF_ADD(2, psteps); RT_PROF_ADD(3, plan); RT_PROF_ADD(4, pch); RT_PROF_ADD(5, ppairs); RT_PROF_ADD(6, 1); RT_PROF_ADD(7, prounds);
+#endif
 }
 
 }  // namespace rt
