@@ -104,22 +104,25 @@ constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 
 // Launches KERNEL<cull, mode>(args...) for run-time cull / traversal mode.
+#define RT_LAUNCH_MODE(KERNEL, CULL, mode, grid, block, stream, ...)                                                \
+    do {                                                                                                            \
+        if ((mode) == MODE_POOL) hipLaunchKernelGGL((KERNEL<CULL, MODE_POOL>), grid, block, 0, stream, __VA_ARGS__);          \
+        else if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<CULL, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);   \
+        else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<CULL, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((KERNEL<CULL, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);                    \
+    } while (0)
 #define RT_LAUNCH2(KERNEL, cull, mode, grid, block, stream, ...)                                                    \
     do {                                                                                                            \
-        if (cull) {                                                                                                 \
-            if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<true, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);       \
-            else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<true, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);    \
-            else hipLaunchKernelGGL((KERNEL<true, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);                \
-        } else {                                                                                                    \
-            if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<false, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);      \
-            else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<false, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((KERNEL<false, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);               \
-        }                                                                                                           \
+        if (cull) RT_LAUNCH_MODE(KERNEL, true, mode, grid, block, stream, __VA_ARGS__);                             \
+        else RT_LAUNCH_MODE(KERNEL, false, mode, grid, block, stream, __VA_ARGS__);                                 \
     } while (0)
 
 template <class... Args>
 void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
-    if (mode == MODE_OCTET) {  // one-wave blocks
+    if (mode == MODE_POOL) {  // one-wave blocks
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_POOL, 1>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_POOL, 1>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_OCTET) {  // one-wave blocks
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_OCTET, 1>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_OCTET, 1>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {  // one-wave blocks
@@ -137,7 +140,9 @@ struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
-    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always eight lanes per ray
+    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always eight lanes per ray, 4 = task pool
+    uint32_t pool_target_waves = 16384, pool_min_rays = 1;
+    mutable bool small_any_query = false;
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
     uint64_t n_tri = 0;
@@ -192,9 +197,25 @@ int traversal_mode(const rt_ads* a, bool coherent_primary, uint64_t n_rays) {
     if (a->traversal == 1 || a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
     if (a->traversal == 2) return MODE_LANE;
     if (a->traversal == 3) return MODE_OCTET;
+    if (a->traversal == 4) return a->shape.max_tris_in_leaf < (1u << kPoolCountBits) ? MODE_POOL : MODE_LANE;
     const bool small_tree = a->use_flat && a->n_flat_tris != 0;
     if (small_tree || a->n_slots < 32768 || coherent_primary) return MODE_WAVE;
-    return n_rays < kOctetMaxRays ? MODE_OCTET : MODE_LANE;
+    if (n_rays < kOctetMaxRays) {
+        const char* e = getenv(coherent_primary ? "RT_SMALL_FORM" : (a->small_any_query ? "RT_SMALL_FORM_ANY" : "RT_SMALL_FORM"));
+        if (e && !strcmp(e, "pool")) return MODE_POOL;
+        if (e && !strcmp(e, "lane")) return MODE_LANE;
+        return MODE_OCTET;
+    }
+    return MODE_LANE;
+}
+
+// Pool form: how many lanes of a wave carry rays (64 >> result).  A launch too small to give every SIMD a few waves
+// is spread over more waves; at least max_group rays (a power of two) stay together.
+uint32_t pool_sparse(const rt_ads* a, int mode, uint64_t n_rays, uint32_t max_group) {
+    if (mode != MODE_POOL) return 0;
+    uint32_t s = 0;
+    while ((64u >> (s + 1)) >= std::max(max_group, a->pool_min_rays) && (n_rays >> (6 - s)) < a->pool_target_waves) ++s;
+    return s;
 }
 
 // Threads per block of k_closest.  Its hit compaction costs one atomic per block and the whole block waits for its
@@ -205,7 +226,10 @@ uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE &&
 template <class... Args>
 void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
     const bool big = block.x > 256;
-    if (mode == MODE_OCTET) {
+    if (mode == MODE_POOL) {
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_POOL, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_POOL, false>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_OCTET) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_OCTET, false>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_OCTET, false>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {
@@ -220,8 +244,12 @@ void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stre
     }
 }
 
-// Threads a launch needs for n rays in the given mode (8 lanes per ray in the octet form).
-uint64_t mode_threads(int mode, uint64_t n_rays) { return mode == MODE_OCTET ? n_rays * 8u : n_rays; }
+// Threads a launch needs for n rays in the given mode (8 lanes per ray in the octet form; whole waves of 64 >> sparse rays).
+uint64_t mode_threads(int mode, uint64_t n_rays, uint32_t sparse = 0) {
+    if (mode == MODE_OCTET) return n_rays * 8u;
+    const uint64_t per_wave = 64u >> sparse;
+    return (n_rays + per_wave - 1) / per_wave * 64u;
+}
 
 int use_device(const rt_ads* a) {
     HIP_TRY(hipSetDevice(a->device));
@@ -680,7 +708,11 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (int rc = a->device_built ? device_build(a) : host_build(a)) return rc;
     if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
     a->traversal = 0;
-    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "octet") ? 3 : 0));
+    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "octet") ? 3 : (!strcmp(e, "pool") ? 4 : 0)));
+    a->pool_target_waves = 16384;
+    a->pool_min_rays = 1;
+    if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
     if (!a->h_counters) HIP_TRY(hipHostMalloc((void**)&a->h_counters, 64 * CNT_WORDS * sizeof(uint32_t)));
     a->built = true;
     return RT_OK;
@@ -821,8 +853,9 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const int mode = traversal_mode(a, false, n);
-    const dim3 block(256), grid((unsigned)((mode_threads(mode, n) + 255) / 256));
-    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri);
+    const uint32_t sparse = pool_sparse(a, mode, n, 1);
+    const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
+    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, sparse);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -856,8 +889,9 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
     const int mode = traversal_mode(a, false, n);
-    const dim3 block(256), grid((unsigned)((mode_threads(mode, n) + 255) / 256));
-    RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out);
+    const uint32_t sparse = pool_sparse(a, mode, n, 1);
+    const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
+    RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
     HIP_TRY(hipGetLastError());
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
@@ -1068,11 +1102,12 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             lv.n = n;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
             const int mode_c = traversal_mode(a, L == 0, n);
-            const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n) + block_c.x - 1) / block_c.x));
+            const uint32_t sparse_c = pool_sparse(a, mode_c, n, 1);
+            const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n, sparse_c) + block_c.x - 1) / block_c.x));
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
             launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
-                       lv.work.p, cnt);
+                       lv.work.p, cnt, sparse_c);
             HIP_TRY(hipGetLastError());
             if (timed_c) {
                 HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream));
@@ -1117,15 +1152,18 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 30) ++pshift;
                 // Per-lane traversal gains from rays of one origin side by side (all lights of a hit in one wave);
                 // the wave-together forms measured faster with one light per pass (a narrower bundle of rays).
+                a->small_any_query = true;
                 const int mode_a = traversal_mode(a, false, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
+                a->small_any_query = false;
                 while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 if (mode_a == MODE_OCTET)  // its visibility bits are or-ed into the words
                     HIP_TRY(hipMemsetAsync(lv.vis.p, 0, (size_t)n_work * a->n_lights * words * sizeof(uint32_t), stream));
                 const dim3 block_a(mode_a == MODE_WAVE ? 256 : 64);
-                const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_work << gshift) + block_a.x - 1) / block_a.x));
+                const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_work << gshift, 1u << gshift);
+                const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_work << gshift, sparse_a) + block_a.x - 1) / block_a.x));
                 launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
-                           lv.work.p, lv.vis.p, words, pshift, gshift, cnt);
+                           lv.work.p, lv.vis.p, words, pshift, gshift, cnt, sparse_a);
                 HIP_TRY(hipGetLastError());
                 if (timed_a) {
                     HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream));
@@ -1228,9 +1266,10 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     }
     const dim3 block(256), grid((n0 + 255) / 256);
     const int mode_c = traversal_mode(a, true, n0);
-    const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0) + block_c.x - 1) / block_c.x));
+    const uint32_t sparse_c = pool_sparse(a, mode_c, n0, 1);
+    const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0, sparse_c) + block_c.x - 1) / block_c.x));
     launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
-               lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p);
+               lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p, sparse_c);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());
@@ -1248,9 +1287,16 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
 }  // extern "C"
 
 #ifdef RT_LANE_PROFILE
-extern "C" int rt_debug_lane_profile(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+extern "C" int rt_debug_lane_profile(unsigned long long* out32) {  // 48 values
+    if (hipMemcpyFromSymbol(out32 + 32, HIP_SYMBOL(rt::g_pool_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pool_prof), z, sizeof z) != hipSuccess) return 1;
+    }
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out32 + 16, HIP_SYMBOL(rt::g_octet_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_octet_prof), z, sizeof z) != hipSuccess) return 1;
     return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof z) != hipSuccess;
 }
 #endif

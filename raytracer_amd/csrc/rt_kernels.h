@@ -21,13 +21,15 @@
 #include "rt_traverse.h"
 #include "rt_traverse_lane.h"
 #include "rt_traverse_octet.h"
+#include "rt_traverse_pool.h"
 
 namespace rt {
 
 // How a kernel walks the tree.  MODE_WAVE: the wave together (rt_traverse.h); MODE_LANE: every lane its own ray
-// (rt_traverse_lane.h); MODE_OCTET: eight lanes per ray (rt_traverse_octet.h) -- a thread index then names lane
-// (index & 7) of ray (index >> 3).  The per-wave stacks of the last two are in LDS; a kernel declares one slot per wave.
-enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_OCTET = 2 };
+// (rt_traverse_lane.h); MODE_OCTET: eight lanes per ray (rt_traverse_octet.h); MODE_POOL: the rays of a wave share
+// a pool of descent tasks (rt_traverse_pool.h).  The per-wave stacks of the last three are in LDS; a kernel declares
+// one slot per wave of its block.
+enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_OCTET = 2, MODE_POOL = 3 };
 template <int MODE>
 struct TraverseLds {
     uint32_t unused;
@@ -40,8 +42,23 @@ template <>
 struct TraverseLds<MODE_OCTET> {
     OctetStackLds s;
 };
+template <>
+struct TraverseLds<MODE_POOL> {
+    PoolLds s;
+};
+// Thread index -> ray index.  MODE_OCTET: thread g is lane (g & 7) of ray (g >> 3).  Otherwise one ray per lane, and
+// only the first 64 >> sparse lanes of a wave carry rays (sparse > 0: small launches of the pool form, whose idle
+// lanes still work on the wave's tasks -- more, shorter waves).  ok: the lane carries a ray.
 template <int MODE>
-__device__ __forceinline__ constexpr uint32_t ray_shift() { return MODE == MODE_OCTET ? 3u : 0u; }
+__device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool& ok) {
+    if (MODE == MODE_OCTET) {
+        ok = true;
+        return g >> 3;
+    }
+    const uint32_t lane = (uint32_t)g & 63u;
+    ok = lane < (64u >> sparse);
+    return ((g >> 6) << (6u - sparse)) + lane;
+}
 // the lane that writes a ray's results
 template <int MODE>
 __device__ __forceinline__ bool ray_lead(uint32_t thread) { return MODE == MODE_OCTET ? (thread & 7u) == 0u : true; }
@@ -49,6 +66,7 @@ template <bool ANY, bool CULL, int MODE>
 __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_OCTET) traverse_octet<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
+    else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
 }
 
@@ -209,10 +227,10 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
 
 template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
-                                                       uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri) {
-    const uint64_t g = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
-    const uint64_t i = g >> ray_shift<MODE>();
-    const bool valid = i < n;
+                                                       uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri, uint32_t sparse) {
+    bool lane_ok;
+    const uint64_t i = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const bool valid = lane_ok && i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (valid) {
         o = mk(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
@@ -229,10 +247,10 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
 
 template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
-                                                   uint64_t n, uint8_t* __restrict__ out) {
-    const uint64_t g = (uint64_t)xcd_block() * blockDim.x + threadIdx.x;
-    const uint64_t i = g >> ray_shift<MODE>();
-    const bool valid = i < n;
+                                                   uint64_t n, uint8_t* __restrict__ out, uint32_t sparse) {
+    bool lane_ok;
+    const uint64_t i = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const bool valid = lane_ok && i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
     if (valid) {
         p = mk(point[i * 3], point[i * 3 + 1], point[i * 3 + 2]);
@@ -280,13 +298,14 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 template <bool CULL, int MODE, bool BIG>
 __global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
-                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ counters) {
-    const uint32_t i = (uint32_t)(((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> ray_shift<MODE>());
+                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ counters, uint32_t sparse) {
+    bool lane_ok;
+    const uint32_t i = (uint32_t)ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     const bool lead = ray_lead<MODE>(threadIdx.x);
     bool valid;
     f3 o, d;
     uint32_t pixel, node_id;
-    load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
+    load_ray(F, rays, level, i, lane_ok ? n : 0u, valid, o, d, pixel, node_id);
     __shared__ TraverseLds<MODE> lds[BIG ? 16 : 4];
     HitState h;
     trace<false, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
@@ -353,14 +372,15 @@ template <bool CULL, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
-                                                uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters) {
+                                                uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters, uint32_t sparse) {
     __shared__ TraverseLds<MODE> lds[WAVES];
-    const uint32_t group = 1u << gshift;
-    const uint64_t ray_slot = ((uint64_t)xcd_block() * blockDim.x + threadIdx.x) >> ray_shift<MODE>();
+    const uint32_t group = 1u << gshift;  // sparse launches: group <= 64 >> sparse, so a group stays inside the lanes of a wave
+    bool lane_ok;
+    const uint64_t ray_slot = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     const uint32_t j = (uint32_t)(ray_slot >> gshift);
     const uint32_t sub = (uint32_t)ray_slot & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
-    const bool active = j < n_work;
+    const bool active = lane_ok && j < n_work;
     uint32_t i = 0;
     if (active) i = work[j];
     bool valid;

@@ -53,22 +53,30 @@ struct LaneStackLds {  // of one wave
     uint32_t hd[64];  // which lane's leaf starts at each position of the current 64-pair chunk
 };
 
+// Wave-wide inclusive scans in six DPP steps (no LDS traffic): shifts by 1, 2, 4, 8 inside each row of 16 lanes (lanes
+// shifted in from outside the row read 0), then lane 15 of row 0 / 2 is added into row 1 / 3 (row_bcast:15) and lane 31
+// into rows 2 and 3 (row_bcast:31).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    const int lane = (int)__lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
+    x += dpp_or_zero<0x111, 0xf>(x);  // row_shr:1
+    x += dpp_or_zero<0x112, 0xf>(x);  // row_shr:2
+    x += dpp_or_zero<0x114, 0xf>(x);  // row_shr:4
+    x += dpp_or_zero<0x118, 0xf>(x);  // row_shr:8
+    x += dpp_or_zero<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+    x += dpp_or_zero<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
     return x;
 }
 __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
-    const int lane = (int)__lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x = x < y ? y : x;
-    }
+    uint32_t y;
+    y = dpp_or_zero<0x111, 0xf>(x); x = x < y ? y : x;
+    y = dpp_or_zero<0x112, 0xf>(x); x = x < y ? y : x;
+    y = dpp_or_zero<0x114, 0xf>(x); x = x < y ? y : x;
+    y = dpp_or_zero<0x118, 0xf>(x); x = x < y ? y : x;
+    y = dpp_or_zero<0x142, 0xa>(x); x = x < y ? y : x;
+    y = dpp_or_zero<0x143, 0xc>(x); x = x < y ? y : x;
     return x;
 }
 

@@ -23,6 +23,13 @@
 
 namespace rt {
 
+#ifdef RT_LANE_PROFILE
+// [ANY][k]: 0 cycles, 1 iterations, 2 iterations with a descent step, 3 groups descending (sum), 4 iterations with a leaf step,
+// 5 groups in a leaf step (sum), 6 waves, 7 triangles tested
+__device__ unsigned long long g_octet_prof[2][8];
+#define RT_OPROF_ADD(k, v) do { if (__lane_id() == 0) atomicAdd(&g_octet_prof[ANY ? 1 : 0][k], (unsigned long long)(v)); } while (0)
+#endif
+
 struct OctetStackLds {  // of one wave
     uint32_t e[kLaneMaxLevels][8];
 };
@@ -75,7 +82,17 @@ __device__ __forceinline__ void traverse_octet(const DevOctree& T, OctetStackLds
         cur_rec = T.root_info0;
         if (active) cur_pending = octet_node_pass(T.nodes, cur_rec, o, inv);
     }
+#ifdef RT_LANE_PROFILE
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pit = 0, pd = 0, pdg = 0, pl = 0, plg = 0, ptri = 0;
+#endif
     while (ballot64(active) != 0) {
+#ifdef RT_LANE_PROFILE
+        {
+            const lanemask md = ballot64(active && leaf_left == 0);
+            ++pit; pd += md != 0; pdg += __builtin_popcountll(md) / 8;
+        }
+#endif
         if (active && leaf_left == 0) {  // one descent step
             if (cur_pending == 0) {
                 if (sp == 0) {
@@ -103,6 +120,13 @@ __device__ __forceinline__ void traverse_octet(const DevOctree& T, OctetStackLds
                 }
             }
         }
+#ifdef RT_LANE_PROFILE
+        {
+            const lanemask ml = ballot64(active && leaf_left != 0);
+            pl += ml != 0; plg += __builtin_popcountll(ml) / 8;
+            ptri += __builtin_popcountll(ballot64(active && leaf_left != 0 && sub < leaf_left));
+        }
+#endif
         if (active && leaf_left != 0) {  // up to 8 triangles of the leaf
             const bool on = sub < leaf_left;
             const uint32_t slot = leaf_slot + sub;
@@ -130,6 +154,10 @@ __device__ __forceinline__ void traverse_octet(const DevOctree& T, OctetStackLds
             }
         }
     }
+#ifdef RT_LANE_PROFILE
+    RT_OPROF_ADD(0, __builtin_amdgcn_s_memtime() - pt0); RT_OPROF_ADD(1, pit); RT_OPROF_ADD(2, pd); RT_OPROF_ADD(3, pdg);
+    RT_OPROF_ADD(4, pl); RT_OPROF_ADD(5, plg); RT_OPROF_ADD(6, 1); RT_OPROF_ADD(7, ptri);
+#endif
     if (ANY) {
         h.found = ballot64(found);
     } else {

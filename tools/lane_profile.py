@@ -28,7 +28,7 @@ kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=
 frame = torch.zeros((H + 64, W, 3), dtype=torch.float32, device="cuda")
 cfg = rt.make_render_config(**kw)
 lib = _capi.lib()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 48)()
 ads.render(cfg, out_ptr=frame.data_ptr())
 torch.cuda.synchronize()
 assert lib.rt_debug_lane_profile(out) == 0
@@ -42,3 +42,17 @@ for k, name in ((0, "closest"), (1, "any-hit")):
     print(f"{name}: waves {waves}  cycles/wave descent {a / waves:.0f} leaf {b / waves:.0f} | per wave: rounds {rounds / waves:.1f} "
           f"descent steps {steps / waves:.1f} (lanes stepping {lanes / max(steps, 1):.1f}) leaf chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
           f"| cycles per descent step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
+for k, name in ((0, "closest"), (1, "any-hit")):
+    cyc, it, d, dg, l, lg, waves, tri = [int(out[16 + k * 8 + i]) for i in range(8)]
+    if waves == 0:
+        continue
+    print(f"octet {name}: waves {waves}  cycles/wave {cyc / waves:.0f}  iterations/wave {it / waves:.1f} (cycles per iteration {cyc / max(it, 1):.0f}) "
+          f"| with descent {d / waves:.1f} (groups {dg / max(d, 1):.1f} of 8) with leaf step {l / waves:.1f} (groups {lg / max(l, 1):.1f}, "
+          f"triangles per leaf step and group {tri / max(lg, 1):.1f})")
+for k, name in ((0, "closest"), (1, "any-hit")):
+    a, b, steps, tasks, chunks, pairs, waves, phases = [int(out[32 + k * 8 + i]) for i in range(8)]
+    if waves == 0:
+        continue
+    print(f"pool {name}: waves {waves}  cycles/wave node steps {a / waves:.0f} leaf {b / waves:.0f} | per wave: node steps {steps / waves:.1f} "
+          f"(tasks per step {tasks / max(steps, 1):.1f}) leaf phases {phases / waves:.1f} chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
+          f"| cycles per node step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
