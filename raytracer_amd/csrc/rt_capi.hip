@@ -141,8 +141,7 @@ struct rt_ads {
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
     int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always eight lanes per ray, 4 = task pool
-    uint32_t pool_target_waves = 16384, pool_min_rays = 1;
-    mutable bool small_any_query = false;
+    uint32_t pool_target_waves = 8192, pool_min_rays = 1;
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
     uint64_t n_tri = 0;
@@ -190,23 +189,21 @@ DevOctree dev_tree(const rt_ads* a) {
 
 // Which traversal a launch of n_rays rays uses.  Small trees are always walked by the wave together (their small-tree
 // form bounds the work by the triangle count).  Large trees: camera rays of an 8x8 pixel tile are coherent and stay
-// wave-together; shadow, secondary and caller-supplied rays are walked per lane -- or, when the launch is too small
-// to fill the chip with one ray per lane, by eight lanes per ray.
-constexpr uint64_t kOctetMaxRays = 1u << 18;
-int traversal_mode(const rt_ads* a, bool coherent_primary, uint64_t n_rays) {
+// wave-together; other rays are walked per lane when the launch is large enough to fill the chip that way.  Smaller
+// launches are bound by the latency of one wave's chain of dependent steps: closest-hit queries then share their
+// descent in a task pool (shortest chains), any-hit queries use eight lanes per ray (keeps the early exit of a
+// depth-first walk).  Measured on a 1.3 M-triangle scene: 88 K rays 400 us per lane, 320 us octet, 133 us pool.
+constexpr uint64_t kPoolMaxRays = 1u << 19, kOctetMaxRays = 1u << 18;
+int traversal_mode(const rt_ads* a, bool coherent_primary, bool any_hit, uint64_t n_rays) {
     if (a->traversal == 1 || a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
+    const bool pool_ok = a->shape.max_tris_in_leaf < (1u << kPoolCountBits);
     if (a->traversal == 2) return MODE_LANE;
     if (a->traversal == 3) return MODE_OCTET;
-    if (a->traversal == 4) return a->shape.max_tris_in_leaf < (1u << kPoolCountBits) ? MODE_POOL : MODE_LANE;
+    if (a->traversal == 4) return pool_ok ? MODE_POOL : MODE_LANE;
     const bool small_tree = a->use_flat && a->n_flat_tris != 0;
     if (small_tree || a->n_slots < 32768 || coherent_primary) return MODE_WAVE;
-    if (n_rays < kOctetMaxRays) {
-        const char* e = getenv(coherent_primary ? "RT_SMALL_FORM" : (a->small_any_query ? "RT_SMALL_FORM_ANY" : "RT_SMALL_FORM"));
-        if (e && !strcmp(e, "pool")) return MODE_POOL;
-        if (e && !strcmp(e, "lane")) return MODE_LANE;
-        return MODE_OCTET;
-    }
-    return MODE_LANE;
+    if (any_hit) return n_rays < kOctetMaxRays ? MODE_OCTET : MODE_LANE;
+    return (n_rays < kPoolMaxRays && pool_ok) ? MODE_POOL : MODE_LANE;
 }
 
 // Pool form: how many lanes of a wave carry rays (64 >> result).  A launch too small to give every SIMD a few waves
@@ -709,7 +706,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
     a->traversal = 0;
     if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "octet") ? 3 : (!strcmp(e, "pool") ? 4 : 0)));
-    a->pool_target_waves = 16384;
+    a->pool_target_waves = 8192;
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
@@ -852,7 +849,7 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
     } else if (mem != RT_MEM_DEVICE) {
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
-    const int mode = traversal_mode(a, false, n);
+    const int mode = traversal_mode(a, false, false, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
     RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, sparse);
@@ -888,7 +885,7 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     } else if (mem != RT_MEM_DEVICE) {
         return fail(RT_ERR_INVALID, "bad mem argument");
     }
-    const int mode = traversal_mode(a, false, n);
+    const int mode = traversal_mode(a, false, true, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
     RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
@@ -1101,7 +1098,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             HIP_TRY(lv.reserve(n, L > 0));
             lv.n = n;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
-            const int mode_c = traversal_mode(a, L == 0, n);
+            const int mode_c = traversal_mode(a, L == 0, false, n);
             const uint32_t sparse_c = pool_sparse(a, mode_c, n, 1);
             const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n, sparse_c) + block_c.x - 1) / block_c.x));
             const bool timed_c = n_timed_closest < kMaxTimed;
@@ -1152,9 +1149,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 30) ++pshift;
                 // Per-lane traversal gains from rays of one origin side by side (all lights of a hit in one wave);
                 // the wave-together forms measured faster with one light per pass (a narrower bundle of rays).
-                a->small_any_query = true;
-                const int mode_a = traversal_mode(a, false, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
-                a->small_any_query = false;
+                const int mode_a = traversal_mode(a, false, true, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
                 while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 if (mode_a == MODE_OCTET)  // its visibility bits are or-ed into the words
@@ -1265,7 +1260,7 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
         d_tri = (int32_t*)(a->d_io.p + npix * 4);
     }
     const dim3 block(256), grid((n0 + 255) / 256);
-    const int mode_c = traversal_mode(a, true, n0);
+    const int mode_c = traversal_mode(a, true, false, n0);
     const uint32_t sparse_c = pool_sparse(a, mode_c, n0, 1);
     const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0, sparse_c) + block_c.x - 1) / block_c.x));
     launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,

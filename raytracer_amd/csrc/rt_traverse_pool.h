@@ -31,11 +31,15 @@ namespace rt {
 #ifndef RT_POOL_ANY_TRIGGER
 #define RT_POOL_ANY_TRIGGER 64
 #endif
-constexpr uint32_t kPoolNodeCap = 1024;  // node tasks: record index (24 bits) | ray << 24
+#ifndef RT_POOL_NODE_CAP
+#define RT_POOL_NODE_CAP 512
+#define RT_POOL_LEAF_CAP 448
+#endif
+constexpr uint32_t kPoolNodeCap = RT_POOL_NODE_CAP;  // node tasks: record index (24 bits) | ray << 24
 constexpr uint32_t kPoolNodeSoft = kPoolNodeCap - 8u * (uint32_t)kLaneMaxLevels;
-constexpr uint32_t kPoolLeafCap = 448;   // leaf items: first slot, triangle count (26 bits) | ray << 26
+constexpr uint32_t kPoolLeafCap = RT_POOL_LEAF_CAP;   // leaf items: first slot, triangle count (26 bits) | ray << 26
 constexpr uint32_t kPoolRecBits = 24, kPoolCountBits = 26;
-static_assert(kPoolLeafCap >= 64 + 8 * 48, "a node step of 48 tasks must fit behind 63 waiting leaf items");
+static_assert(kPoolLeafCap >= 64 + 8 * 8, "a node step must fit behind 63 waiting leaf items");
 
 #ifdef RT_LANE_PROFILE
 // [ANY][k]: 0 cycles in node steps, 1 cycles in leaf work, 2 node steps, 3 tasks taken, 4 leaf chunks, 5 pairs, 6 waves, 7 leaf phases
