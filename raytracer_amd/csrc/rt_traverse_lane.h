@@ -48,6 +48,10 @@ __device__ unsigned long long g_lane_prof[2][8];
 #define RT_PROF_ADD(k, v) do { if (__lane_id() == 0) atomicAdd(&g_lane_prof[ANY ? 1 : 0][k], (unsigned long long)(v)); } while (0)
 #endif
 
+// Cross-lane traffic through LDS goes through volatile pointers in the LDS address space (ds_read / ds_write); a
+// volatile generic pointer would compile to flat accesses with a wait after each.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+
 struct LaneStackLds {  // of one wave
     uint32_t e[kLaneMaxLevels][64];
     uint32_t hd[64];  // which lane's leaf starts at each position of the current 64-pair chunk
@@ -205,7 +209,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            volatile uint32_t* hd = stk.hd;
+            lds_vu32* hd = (lds_vu32*)stk.hd;
             lanemask decided = 0;  // any-hit: owners that found an occluder earlier in this round
             for (uint32_t base = 0; base < total; base += 64) {
                 hd[lane] = 0;

@@ -67,10 +67,10 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
     if (T.root_info1 == 0 || vm == 0) return;  // empty tree / no rays
     const uint32_t lane = __lane_id();
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
-    volatile uint32_t* nstk = lds.nodes;
-    volatile uint32_t* lslot = lds.leaf_slot;
-    volatile uint32_t* lcount = lds.leaf_count;
-    volatile uint32_t* hd = lds.hd;
+    lds_vu32* nstk = (lds_vu32*)lds.nodes;
+    lds_vu32* lslot = (lds_vu32*)lds.leaf_slot;
+    lds_vu32* lcount = (lds_vu32*)lds.leaf_count;
+    lds_vu32* hd = (lds_vu32*)lds.hd;
     uint32_t ns = (uint32_t)__builtin_popcountll(vm), nl = 0;  // wave-uniform fill levels
     if (valid) nstk[__builtin_popcountll(vm & ((1ull << lane) - 1ull))] = T.root_info0 | (lane << kPoolRecBits);
     if (!ANY) lds.best[lane] = ~0ull;
