@@ -107,7 +107,6 @@ constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 #define RT_LAUNCH_MODE(KERNEL, CULL, mode, grid, block, stream, ...)                                                \
     do {                                                                                                            \
         if ((mode) == MODE_POOL) hipLaunchKernelGGL((KERNEL<CULL, MODE_POOL>), grid, block, 0, stream, __VA_ARGS__);          \
-        else if ((mode) == MODE_OCTET) hipLaunchKernelGGL((KERNEL<CULL, MODE_OCTET>), grid, block, 0, stream, __VA_ARGS__);   \
         else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<CULL, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);     \
         else hipLaunchKernelGGL((KERNEL<CULL, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);                    \
     } while (0)
@@ -122,9 +121,6 @@ void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t strea
     if (mode == MODE_POOL) {  // one-wave blocks
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_POOL, 1>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_POOL, 1>), grid, block, 0, stream, args...);
-    } else if (mode == MODE_OCTET) {  // one-wave blocks
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_OCTET, 1>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_OCTET, 1>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {  // one-wave blocks
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_LANE, 1>), grid, block, 0, stream, args...);
@@ -140,7 +136,7 @@ struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
-    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always eight lanes per ray, 4 = task pool
+    int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always the task pool
     uint32_t pool_target_waves = 8192, pool_min_rays = 1;
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
@@ -190,20 +186,18 @@ DevOctree dev_tree(const rt_ads* a) {
 // Which traversal a launch of n_rays rays uses.  Small trees are always walked by the wave together (their small-tree
 // form bounds the work by the triangle count).  Large trees: camera rays of an 8x8 pixel tile are coherent and stay
 // wave-together; other rays are walked per lane when the launch is large enough to fill the chip that way.  Smaller
-// launches are bound by the latency of one wave's chain of dependent steps: closest-hit queries then share their
-// descent in a task pool (shortest chains), any-hit queries use eight lanes per ray (keeps the early exit of a
-// depth-first walk).  Measured on a 1.3 M-triangle scene: 88 K rays 400 us per lane, 320 us octet, 133 us pool.
-constexpr uint64_t kPoolMaxRays = 1u << 19, kOctetMaxRays = 1u << 18;
+// launches are bound by the latency of one wave's chain of dependent steps and share their descent in a task pool
+// (measured on a 1.3 M-triangle scene, 88 K closest-hit rays: 400 us per lane, 120 us pool; break-even near half a
+// million closest-hit and a quarter million any-hit rays).
+constexpr uint64_t kPoolMaxRaysClosest = 1u << 19, kPoolMaxRaysAny = 1u << 18;
 int traversal_mode(const rt_ads* a, bool coherent_primary, bool any_hit, uint64_t n_rays) {
     if (a->traversal == 1 || a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
     const bool pool_ok = a->shape.max_tris_in_leaf < (1u << kPoolCountBits);
     if (a->traversal == 2) return MODE_LANE;
-    if (a->traversal == 3) return MODE_OCTET;
-    if (a->traversal == 4) return pool_ok ? MODE_POOL : MODE_LANE;
+    if (a->traversal == 3) return pool_ok ? MODE_POOL : MODE_LANE;
     const bool small_tree = a->use_flat && a->n_flat_tris != 0;
     if (small_tree || a->n_slots < 32768 || coherent_primary) return MODE_WAVE;
-    if (any_hit) return n_rays < kOctetMaxRays ? MODE_OCTET : MODE_LANE;
-    return (n_rays < kPoolMaxRays && pool_ok) ? MODE_POOL : MODE_LANE;
+    return (pool_ok && n_rays < (any_hit ? kPoolMaxRaysAny : kPoolMaxRaysClosest)) ? MODE_POOL : MODE_LANE;
 }
 
 // Pool form: how many lanes of a wave carry rays (64 >> result).  A launch too small to give every SIMD a few waves
@@ -226,9 +220,6 @@ void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stre
     if (mode == MODE_POOL) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_POOL, false>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_POOL, false>), grid, block, 0, stream, args...);
-    } else if (mode == MODE_OCTET) {
-        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_OCTET, false>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_closest<false, MODE_OCTET, false>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_LANE, false>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_LANE, false>), grid, block, 0, stream, args...);
@@ -241,9 +232,8 @@ void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stre
     }
 }
 
-// Threads a launch needs for n rays in the given mode (8 lanes per ray in the octet form; whole waves of 64 >> sparse rays).
-uint64_t mode_threads(int mode, uint64_t n_rays, uint32_t sparse = 0) {
-    if (mode == MODE_OCTET) return n_rays * 8u;
+// Threads a launch needs for n rays: whole waves of 64 >> sparse rays.
+uint64_t mode_threads(int, uint64_t n_rays, uint32_t sparse = 0) {
     const uint64_t per_wave = 64u >> sparse;
     return (n_rays + per_wave - 1) / per_wave * 64u;
 }
@@ -705,7 +695,7 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (int rc = a->device_built ? device_build(a) : host_build(a)) return rc;
     if (const char* e = getenv("RT_DISABLE_SMALL_TREE")) a->use_flat = !(e[0] == '1');
     a->traversal = 0;
-    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "octet") ? 3 : (!strcmp(e, "pool") ? 4 : 0)));
+    if (const char* e = getenv("RT_TRAVERSAL")) a->traversal = !strcmp(e, "wave") ? 1 : (!strcmp(e, "lane") ? 2 : (!strcmp(e, "pool") ? 3 : 0));
     a->pool_target_waves = 8192;
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
@@ -1152,8 +1142,6 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 const int mode_a = traversal_mode(a, false, true, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
                 while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
-                if (mode_a == MODE_OCTET)  // its visibility bits are or-ed into the words
-                    HIP_TRY(hipMemsetAsync(lv.vis.p, 0, (size_t)n_work * a->n_lights * words * sizeof(uint32_t), stream));
                 const dim3 block_a(mode_a == MODE_WAVE ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_work << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_work << gshift, sparse_a) + block_a.x - 1) / block_a.x));
@@ -1289,9 +1277,8 @@ extern "C" int rt_debug_lane_profile(unsigned long long* out32) {  // 48 values
         if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pool_prof), z, sizeof z) != hipSuccess) return 1;
     }
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(out32 + 16, HIP_SYMBOL(rt::g_octet_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_octet_prof), z, sizeof z) != hipSuccess) return 1;
+    for (int i = 16; i < 32; ++i) out32[i] = 0;
     return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof z) != hipSuccess;
 }
 #endif

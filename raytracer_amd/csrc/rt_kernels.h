@@ -20,16 +20,14 @@
 
 #include "rt_traverse.h"
 #include "rt_traverse_lane.h"
-#include "rt_traverse_octet.h"
 #include "rt_traverse_pool.h"
 
 namespace rt {
 
 // How a kernel walks the tree.  MODE_WAVE: the wave together (rt_traverse.h); MODE_LANE: every lane its own ray
-// (rt_traverse_lane.h); MODE_OCTET: eight lanes per ray (rt_traverse_octet.h); MODE_POOL: the rays of a wave share
-// a pool of descent tasks (rt_traverse_pool.h).  The per-wave stacks of the last three are in LDS; a kernel declares
-// one slot per wave of its block.
-enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_OCTET = 2, MODE_POOL = 3 };
+// (rt_traverse_lane.h); MODE_POOL: the rays of a wave share a pool of descent tasks (rt_traverse_pool.h).  The
+// per-wave stacks of the last two are in LDS; a kernel declares one slot per wave of its block.
+enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_POOL = 2 };
 template <int MODE>
 struct TraverseLds {
     uint32_t unused;
@@ -39,33 +37,20 @@ struct TraverseLds<MODE_LANE> {
     LaneStackLds s;
 };
 template <>
-struct TraverseLds<MODE_OCTET> {
-    OctetStackLds s;
-};
-template <>
 struct TraverseLds<MODE_POOL> {
     PoolLds s;
 };
-// Thread index -> ray index.  MODE_OCTET: thread g is lane (g & 7) of ray (g >> 3).  Otherwise one ray per lane, and
-// only the first 64 >> sparse lanes of a wave carry rays (sparse > 0: small launches of the pool form, whose idle
-// lanes still work on the wave's tasks -- more, shorter waves).  ok: the lane carries a ray.
-template <int MODE>
+// Thread index -> ray index: one ray per lane, and only the first 64 >> sparse lanes of a wave carry rays (sparse > 0:
+// small launches of the pool form, whose idle lanes still work on the wave's tasks -- more, shorter waves).
+// ok: the lane carries a ray.
 __device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool& ok) {
-    if (MODE == MODE_OCTET) {
-        ok = true;
-        return g >> 3;
-    }
     const uint32_t lane = (uint32_t)g & 63u;
     ok = lane < (64u >> sparse);
     return ((g >> 6) << (6u - sparse)) + lane;
 }
-// the lane that writes a ray's results
-template <int MODE>
-__device__ __forceinline__ bool ray_lead(uint32_t thread) { return MODE == MODE_OCTET ? (thread & 7u) == 0u : true; }
 template <bool ANY, bool CULL, int MODE>
 __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
-    else if constexpr (MODE == MODE_OCTET) traverse_octet<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
 }
@@ -229,7 +214,7 @@ template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
                                                        uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri, uint32_t sparse) {
     bool lane_ok;
-    const uint64_t i = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     const bool valid = lane_ok && i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (valid) {
@@ -239,7 +224,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
     __shared__ TraverseLds<MODE> lds[4];
     HitState h;
     trace<false, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
-    if (valid && ray_lead<MODE>(threadIdx.x)) {
+    if (valid) {
         out_t[i] = h.t;
         out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
     }
@@ -249,7 +234,7 @@ template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
                                                    uint64_t n, uint8_t* __restrict__ out, uint32_t sparse) {
     bool lane_ok;
-    const uint64_t i = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     const bool valid = lane_ok && i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
     if (valid) {
@@ -263,7 +248,7 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     __shared__ TraverseLds<MODE> lds[4];
     HitState h;
     trace<true, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, p, d, dist, h);
-    if (valid && ray_lead<MODE>(threadIdx.x)) out[i] = lane_of(h.found) ? 1 : 0;
+    if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
 // ---- renderer level kernels ------------------------------------------------------------------------------------
@@ -300,8 +285,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameP
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters, uint32_t sparse) {
     bool lane_ok;
-    const uint32_t i = (uint32_t)ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
-    const bool lead = ray_lead<MODE>(threadIdx.x);
+    const uint32_t i = (uint32_t)ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     bool valid;
     f3 o, d;
     uint32_t pixel, node_id;
@@ -309,8 +293,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameP
     __shared__ TraverseLds<MODE> lds[BIG ? 16 : 4];
     HitState h;
     trace<false, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
-    const bool hit = valid && lead && !(h.t == RT_INF);
-    if (valid && lead) {
+    const bool hit = valid && !(h.t == RT_INF);
+    if (valid) {
         hit_t[i] = h.t;
         hit_tri[i] = hit ? (int32_t)h.tri : -1;
         if (!hit) {  // renderer.cc:140-142: the background colour is this node's value
@@ -364,9 +348,7 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // the lights, rays of one origin side by side, and a launch has enough waves to fill the chip even for a few thousand
 // hits.  The result is one visibility bit per (light, sample): vis[(l * words + s / 32) * n_work + j] bit s % 32 = 1
 // if not shadowed (hit j innermost); the bits of a word come from one ballot, so no two lanes write the same word.
-// MODE_OCTET (small launches): every ray has 8 lanes, the rays of a visibility word may sit in several waves, and the
-// bits are set with atomicOr into words the host has zeroed.
-// WAVES: waves per block.  The kernel has no block-level step, so the per-lane and octet forms run one-wave blocks:
+// WAVES: waves per block.  The kernel has no block-level step, so the per-lane and pool forms run one-wave blocks:
 // a wave that finishes frees its slot at once instead of waiting for the slowest of four.
 template <bool CULL, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
@@ -376,7 +358,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F
     __shared__ TraverseLds<MODE> lds[WAVES];
     const uint32_t group = 1u << gshift;  // sparse launches: group <= 64 >> sparse, so a group stays inside the lanes of a wave
     bool lane_ok;
-    const uint64_t ray_slot = ray_index<MODE>((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t ray_slot = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     const uint32_t j = (uint32_t)(ray_slot >> gshift);
     const uint32_t sub = (uint32_t)ray_slot & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
@@ -413,7 +395,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F
         const lanemask on_mask = ballot64(on);
         if (on_mask == 0) continue;
         // one light per pass (group == samples per light): its record is wave-uniform and comes through scalar loads
-        const uint32_t l_load = (MODE != MODE_OCTET && gshift <= pshift) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
+        const uint32_t l_load = gshift <= pshift ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)) : (lit ? l : 0u);
         const LightDev& L = S.lights[l_load];
         const f3 p_l = light_sample(L, pre, l, smp);
         // renderer.cc:289-290
@@ -424,13 +406,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F
         trace<true, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], on, P, d_l, dist, h);
         const lanemask unshadowed = on_mask & ~h.found;
         const uint32_t word = smp >> 5;
-        if constexpr (MODE == MODE_OCTET) {
-            if (lane_of(unshadowed) && ray_lead<MODE>(threadIdx.x) && word < words)
-                atomicOr(&vis[((size_t)l * words + word) * n_work + j], 1u << (smp & 31u));
-        } else {
-            if (lit && writer && word < words)
-                vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
-        }
+        if (lit && writer && word < words)
+            vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
     }
 }
 

@@ -115,10 +115,10 @@ def test_small_tree_form_equals_general_form(rt, orc, scenes, monkeypatch):
     assert len(verts) > 0
 
 
-@pytest.mark.parametrize("mode", ["wave", "lane", "octet", "pool"])
+@pytest.mark.parametrize("mode", ["wave", "lane", "pool"])
 @pytest.mark.parametrize("scene,mb,md", [("sphere", 16, 10), ("sphere", 4, 3), ("original", 8, 2), ("original", 1000, 10)])
 def test_both_traversals(rt, orc, scenes, monkeypatch, mode, scene, mb, md):
-    """The traversal kernels (the wave walks together / every lane walks its own ray / eight lanes per ray) are forced in
+    """The traversal kernels (the wave walks together / every lane walks its own ray / the rays of a wave share a task pool) are forced in
     turn and must each reproduce the oracle: closest hits, occlusion flags and a rendered frame with shadow and secondary rays."""
     monkeypatch.setenv("RT_TRAVERSAL", mode)
     monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
@@ -176,7 +176,7 @@ def test_empty_and_tiny_scenes(rt, orc, scenes):
     assert np.array_equal(g.Search(np.concatenate([o[0], d[0]])), np.arange(5))
 
 
-@pytest.mark.parametrize("mode", ["auto", "wave", "lane", "octet", "pool"])
+@pytest.mark.parametrize("mode", ["auto", "wave", "lane", "pool"])
 @pytest.mark.parametrize("scene", ["original", "sphere"])
 def test_degenerate_rays_and_ragged_batches(rt, orc, scenes, monkeypatch, scene, mode):
     """Zero, denormal, huge, infinite and NaN ray components take the inf / NaN branches of the slab and triangle tests;
@@ -510,7 +510,7 @@ def test_full_size_frame_properties(rt, orc, scenes, monkeypatch):
     assert np.abs(full[536:544] - ref[536:544]).max() <= 1.0 / 255.0
     # the other traversal forms
     for env in ({"RT_DISABLE_SMALL_TREE": "1"}, {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"},
-                {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "octet"}, {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"}):
+                {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g2 = build(rt, sc)
@@ -528,7 +528,7 @@ def test_full_size_frame_properties(rt, orc, scenes, monkeypatch):
 
 
 @pytest.mark.parametrize("spt", [3, 5, 33, 70])
-@pytest.mark.parametrize("mode", ["auto", "lane", "octet", "pool"])
+@pytest.mark.parametrize("mode", ["auto", "lane", "pool"])
 def test_light_sample_layouts(rt, orc, scenes, monkeypatch, spt, mode):
     """Sample counts that are not powers of two, exceed one visibility word (32) or one wave (64), with three lights
     (one more triangle made emissive): the any-hit pass spreads (light, sample) pairs over lane groups differently
@@ -558,7 +558,7 @@ def test_large_tree_frame_properties(rt, monkeypatch):
     cam = CAMERAS["original"]
     cfg = rt.make_render_config(fov=0.6, width=1920, height=1080, spt=1, render_type="phong", shading="flat", aspect_mode=1, **cam)
     frames = []
-    for builder, traversal in (("device", "auto"), ("host", "auto"), ("device", "wave"), ("device", "lane"), ("device", "octet"), ("device", "pool")):
+    for builder, traversal in (("device", "auto"), ("host", "auto"), ("device", "wave"), ("device", "lane"), ("device", "pool")):
         monkeypatch.setenv("RT_TRAVERSAL", traversal)
         g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10, "builder": builder})
         g.Build(s.pos)

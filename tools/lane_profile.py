@@ -43,13 +43,6 @@ for k, name in ((0, "closest"), (1, "any-hit")):
           f"descent steps {steps / waves:.1f} (lanes stepping {lanes / max(steps, 1):.1f}) leaf chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
           f"| cycles per descent step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
 for k, name in ((0, "closest"), (1, "any-hit")):
-    cyc, it, d, dg, l, lg, waves, tri = [int(out[16 + k * 8 + i]) for i in range(8)]
-    if waves == 0:
-        continue
-    print(f"octet {name}: waves {waves}  cycles/wave {cyc / waves:.0f}  iterations/wave {it / waves:.1f} (cycles per iteration {cyc / max(it, 1):.0f}) "
-          f"| with descent {d / waves:.1f} (groups {dg / max(d, 1):.1f} of 8) with leaf step {l / waves:.1f} (groups {lg / max(l, 1):.1f}, "
-          f"triangles per leaf step and group {tri / max(lg, 1):.1f})")
-for k, name in ((0, "closest"), (1, "any-hit")):
     a, b, steps, tasks, chunks, pairs, waves, phases = [int(out[32 + k * 8 + i]) for i in range(8)]
     if waves == 0:
         continue
