@@ -40,6 +40,7 @@ constexpr uint32_t kPoolNodeSoft = kPoolNodeCap - 8u * (uint32_t)kLaneMaxLevels;
 constexpr uint32_t kPoolLeafCap = RT_POOL_LEAF_CAP;   // leaf items: first slot, triangle count (26 bits) | ray << 26
 constexpr uint32_t kPoolRecBits = 24, kPoolCountBits = 26;
 static_assert(kPoolLeafCap >= 64 + 8 * 8, "a node step must fit behind 63 waiting leaf items");
+static_assert(kPoolNodeSoft >= 64, "the 64 root tasks of a wave must fit under the soft limit");
 
 #ifdef RT_LANE_PROFILE
 // [ANY][k]: 0 cycles in node steps, 1 cycles in leaf work, 2 node steps, 3 tasks taken, 4 leaf chunks, 5 pairs, 6 waves, 7 leaf phases

@@ -87,6 +87,46 @@ def test_trace_any(rt, orc, scenes, scene):
         assert 0 < ref.sum() < ref.size
 
 
+def test_task_pool_under_capacity_pressure(rt, scenes, monkeypatch, tmp_path):
+    """The task-pool traversal bounds its LDS pool: a step takes fewer tasks when the pool is nearly full and a single
+    one beyond the soft limit.  The product's capacities rarely get there, so a variant of the library built with tiny
+    capacities (72 tasks soft limit, 128 leaf items; `make stress`) walks a deep tree (2 triangles per leaf, depth 12)
+    with bundles of 64 rays and must give the same hits and occlusion flags, bit for bit, as the per-lane form of the
+    product library."""
+    import os
+    import subprocess
+    import sys
+    from raytracer_amd import _capi
+    from raytracer_amd.synthetic import cornell_with_icosphere
+    stress = os.path.join(os.path.dirname(_capi.LIB_PATH), "libraytracer_amd_poolstress.so")
+    assert os.path.exists(stress), "build it with `make -C raytracer_amd/csrc stress` (__graft_entry__.build() does)"
+    sc = cornell_with_icosphere(scenes["original"], 5)
+    o, d = random_rays(sc, 60000, 23)
+    # coherent bundles: 64 neighbouring rays from one point towards the sphere
+    rs = np.random.RandomState(5)
+    centre = np.array([278.0, 200.0, 280.0], np.float32)
+    ob = np.repeat((centre + rs.randn(400, 3) * 300).astype(np.float32), 64, axis=0)
+    db = centre - ob + rs.randn(len(ob), 3).astype(np.float32) * 40
+    db = (db / np.linalg.norm(db, axis=1, keepdims=True)).astype(np.float32)
+    o, d = np.concatenate([o, ob]), np.concatenate([d, db])
+    P = o[:40000].copy()
+    L = (P + d[:40000] * 500.0).astype(np.float32)
+    monkeypatch.setenv("RT_TRAVERSAL", "lane")
+    g = rt.GpuOctree({"max_triangles_per_BB": 2, "max_depth": 12})
+    g.Build(sc.pos)
+    t_ref, tri_ref = g.trace_closest(o, d, True)
+    occ_ref = g.trace_any(P, L, True)
+    assert (tri_ref >= 0).sum() > 10000 and 0 < occ_ref.sum() < occ_ref.size
+    fin, fout = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(fin, pos=sc.pos, o=o, d=d, P=P, L=L, mb=2, md=12)
+    env = dict(os.environ, RT_LIB_PATH=stress, RT_TRAVERSAL="pool")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "pool_stress_child.py"), fin, fout], env=env, check=True,
+                   timeout=200)
+    got = np.load(fout)
+    assert np.array_equal(got["tri"], tri_ref) and np.array_equal(bits(got["t"]), bits(t_ref))
+    assert np.array_equal(got["occ"], occ_ref)
+
+
 def test_small_tree_form_equals_general_form(rt, orc, scenes, monkeypatch):
     """Trees with at most 32 leaves are traversed in a special form (one pass over the triangle array with
     per-lane leaf-reach masks).  It must give the same hits as the general leaf-by-leaf traversal, ties included:
