@@ -78,4 +78,23 @@ RT_HD uint32_t rng_finish(uint32_t prefix, uint32_t light, uint32_t sample, uint
 }
 RT_HD float u31_to_float(uint32_t k) { return (float)(int32_t)k / 2147483648.0f; }  // (float)RAND_MAX == 2^31
 
+#if defined(__HIPCC__)
+// 1.0f / d without the bookkeeping of a general division.  The compiler expands an IEEE f32 division into two
+// v_div_scale, v_rcp, a refinement chain of fused multiply-adds, v_div_fmas and v_div_fixup -- 43 cycles per wave
+// (tools/valu_ops.hip), as much as 18 multiplications.  The scale and fixup steps only act on operands near the ends
+// of the exponent range; elsewhere the quotient is the refinement chain alone, which is what this function computes.
+// tools/rcp_check.hip compares it with 1.0f / d for EVERY float with kEps <= |d| <= kRcpFastMax: identical bits.
+// Callers must use the true division outside that range.
+constexpr float kRcpFastMax = 0x1p40f;
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(e1, r1, r1);
+    const float e2 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(e2, r1, q1);
+}
+#endif
+
 }  // namespace rt

@@ -68,7 +68,11 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
     const float d = dot(e1, p);
     lanemask ok = mine & ~ballot64(CULL ? (d < kEps) : (fabsf(d) < kEps));
     if (ok == 0) return 0;
-    const float d_inv = 1.0f / d;
+    // 1 / d: the lanes of `ok` have |d| >= kEps; if none of them exceeds kRcpFastMax either, the refinement chain of
+    // rt_math.h gives the bits of the division at half its cost (the other lanes' quotients are never used)
+    float d_inv;
+    if ((ok & ballot64(fabsf(d) > kRcpFastMax)) == 0) d_inv = rcp_refined(d);
+    else d_inv = 1.0f / d;
     const f3 q = o - a;
     const float u = d_inv * dot(q, p);
     ok &= ~(ballot64(u < 0.0f) | ballot64(u > 1.0f));
