@@ -79,6 +79,16 @@ RT_HD uint32_t rng_finish(uint32_t prefix, uint32_t light, uint32_t sample, uint
 RT_HD float u31_to_float(uint32_t k) { return (float)(int32_t)k / 2147483648.0f; }  // (float)RAND_MAX == 2^31
 
 #if defined(__HIPCC__)
+// Running maximum / minimum of the slab test (collision_detection.h:82-83 uses std::max / std::min: a NaN second
+// argument is ignored, a NaN first argument would be kept).  The first argument is the running value: it starts at
+// -inf / +inf and is only ever replaced by a second argument that compared greater / smaller, so it is never NaN; and
+// with a non-NaN first argument the hardware maximum (which also ignores a NaN second argument -- a product, never a
+// signaling NaN) returns the same value up to the sign of a zero.  The only use of the results is the comparison
+// t_max >= t_min, which the sign of a zero does not change.  v_max_f32 / v_min_f32 are single full-rate instructions
+// where compare-and-select is two half-rate ones plus a wait state (tools/valu_ops.hip).
+__device__ __forceinline__ float slab_max(float running, float b) { return __builtin_fmaxf(running, b); }
+__device__ __forceinline__ float slab_min(float running, float b) { return __builtin_fminf(running, b); }
+
 // 1.0f / d without the bookkeeping of a general division.  The compiler expands an IEEE f32 division into two
 // v_div_scale, v_rcp, a refinement chain of fused multiply-adds, v_div_fmas and v_div_fixup -- 43 cycles per wave
 // (tools/valu_ops.hip), as much as 18 multiplications.  The scale and fixup steps only act on operands near the ends

@@ -299,11 +299,11 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
                 if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
                 const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
                 // collision_detection.h:72-85 in its order: x, then y, then z
-                float t_min = std_max(-RT_INF, tn[0][bx]), t_max = std_min(RT_INF, tf[0][bx]);
-                t_min = std_max(t_min, tn[1][by]);
-                t_max = std_min(t_max, tf[1][by]);
-                t_min = std_max(t_min, tn[2][bz]);
-                t_max = std_min(t_max, tf[2][bz]);
+                float t_min = slab_max(-RT_INF, tn[0][bx]), t_max = slab_min(RT_INF, tf[0][bx]);
+                t_min = slab_max(t_min, tn[1][by]);
+                t_max = slab_min(t_max, tf[1][by]);
+                t_min = slab_max(t_min, tn[2][bz]);
+                t_max = slab_min(t_max, tf[2][bz]);
                 const lanemask pm = mine & ballot64(t_max >= t_min);
                 if (pm == 0) continue;
                 if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;

@@ -109,11 +109,11 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-        float t_min = std_max(-RT_INF, tn[0][bx]), t_max = std_min(RT_INF, tf[0][bx]);
-        t_min = std_max(t_min, tn[1][by]);
-        t_max = std_min(t_max, tf[1][by]);
-        t_min = std_max(t_min, tn[2][bz]);
-        t_max = std_min(t_max, tf[2][bz]);
+        float t_min = slab_max(-RT_INF, tn[0][bx]), t_max = slab_min(RT_INF, tf[0][bx]);
+        t_min = slab_max(t_min, tn[1][by]);
+        t_max = slab_min(t_max, tf[1][by]);
+        t_min = slab_max(t_min, tn[2][bz]);
+        t_max = slab_min(t_max, tf[2][bz]);
         pass |= (t_max >= t_min) ? (1u << c) : 0u;
     }
     return pass & nonempty;
