@@ -32,8 +32,67 @@ RT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 RT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 RT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
 RT_HD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+#if defined(__HIPCC__)
+// Division on the device.  The compiler expands an IEEE f32 division into two v_div_scale, v_rcp, a refinement chain
+// of fused multiply-adds, v_div_fmas and v_div_fixup -- 43 cycles per wave (tools/valu_ops.hip), as much as 18
+// multiplications.  The scale and fixup steps only act on operands near the ends of the exponent range (zero,
+// denormal, huge, or far apart); elsewhere the quotient is the refinement chain alone, which is what the functions
+// below compute.  Callers use them only where every lane that matters has both operands within
+// [kDivFastMin, kDivFastMax] in magnitude, and the true division otherwise.  tools/rcp_check.hip compares
+// rcp_refined with 1.0f / d for EVERY float in the range and div_refined with n / d for billions of operand pairs
+// (random and extreme mantissas): identical bits.
+constexpr float kDivFastMin = 0x1p-40f, kDivFastMax = 0x1p40f;
+constexpr float kRcpFastMax = kDivFastMax;
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(e1, r1, r1);
+    const float e2 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(e2, r1, q1);
+}
+// 1 / d per component (collision_detection.h:76) for the lanes with `need`; the other lanes get unspecified values
+__device__ __forceinline__ f3 reciprocal3(f3 d, bool need);
+// r1: the once-refined reciprocal of d, shared by all numerators of the same denominator
+__device__ __forceinline__ float div_refined_r1(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_refined(float n, float d, float r1) {
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r1, q1);
+}
+#endif
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ f3 reciprocal3(f3 d, bool need) {
+    const float lo = __builtin_fminf(__builtin_fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const bool in_range = lo >= kEps && hi <= kDivFastMax;  // the range rcp_refined is checked on (false for NaN)
+    if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) return f3{rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z)};
+    return f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+}
+#endif
+
 // src/vec3.h:25 -- guarded division: |s| <= eps gives the zero vector.
-RT_HD f3 div_guard(f3 a, float s) { return fabsf(s) > kEps ? f3{a.x / s, a.y / s, a.z / s} : f3{0.f, 0.f, 0.f}; }
+RT_HD f3 div_guard(f3 a, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the refinement chain with one shared reciprocal when the operands of every active lane that divides are in range
+    const bool divides = fabsf(s) > kEps;
+    const float lo = __builtin_fminf(__builtin_fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)), fabsf(s));
+    const bool in_range = lo >= kDivFastMin && hi <= kDivFastMax;  // (false for NaN operands)
+    if (__builtin_amdgcn_ballot_w64(divides && !in_range) == 0) {
+        const float r1 = div_refined_r1(s);
+        return divides ? f3{div_refined(a.x, s, r1), div_refined(a.y, s, r1), div_refined(a.z, s, r1)} : f3{0.f, 0.f, 0.f};
+    }
+#endif
+    return fabsf(s) > kEps ? f3{a.x / s, a.y / s, a.z / s} : f3{0.f, 0.f, 0.f};
+}
 // src/vec3.h:32 -- epsilon equality.
 RT_HD bool eq_eps(f3 a, f3 b) { return fabsf(a.x - b.x) < kEps && fabsf(a.y - b.y) < kEps && fabsf(a.z - b.z) < kEps; }
 RT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -89,22 +148,6 @@ RT_HD float u31_to_float(uint32_t k) { return (float)(int32_t)k / 2147483648.0f;
 __device__ __forceinline__ float slab_max(float running, float b) { return __builtin_fmaxf(running, b); }
 __device__ __forceinline__ float slab_min(float running, float b) { return __builtin_fminf(running, b); }
 
-// 1.0f / d without the bookkeeping of a general division.  The compiler expands an IEEE f32 division into two
-// v_div_scale, v_rcp, a refinement chain of fused multiply-adds, v_div_fmas and v_div_fixup -- 43 cycles per wave
-// (tools/valu_ops.hip), as much as 18 multiplications.  The scale and fixup steps only act on operands near the ends
-// of the exponent range; elsewhere the quotient is the refinement chain alone, which is what this function computes.
-// tools/rcp_check.hip compares it with 1.0f / d for EVERY float with kEps <= |d| <= kRcpFastMax: identical bits.
-// Callers must use the true division outside that range.
-constexpr float kRcpFastMax = 0x1p40f;
-__device__ __forceinline__ float rcp_refined(float d) {
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
-    const float q1 = __builtin_fmaf(e1, r1, r1);
-    const float e2 = __builtin_fmaf(-d, q1, 1.0f);
-    return __builtin_fmaf(e2, r1, q1);
-}
 #endif
 
 }  // namespace rt

@@ -266,7 +266,7 @@ struct WaveStack {
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
 template <bool ANY, bool CULL, bool FLAT>
 __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
+    const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
     WaveStack st;
     uint32_t reach = 0;
     cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);

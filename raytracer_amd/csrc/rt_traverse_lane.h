@@ -128,7 +128,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
     h.found = 0;
     if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
     const uint32_t tid = __lane_id();
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
+    const f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
     bool active = valid;
     bool found = false;
     constexpr bool kTwo = ANY ? (RT_LANE_TWO_LEAVES_ANY != 0) : (RT_LANE_TWO_LEAVES_CLOSEST != 0);

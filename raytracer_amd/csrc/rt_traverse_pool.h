@@ -67,7 +67,7 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
     const lanemask vm = ballot64(valid);
     if (T.root_info1 == 0 || vm == 0) return;  // empty tree / no rays
     const uint32_t lane = __lane_id();
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // collision_detection.h:76
+    const f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
     lds_vu32* nstk = (lds_vu32*)lds.nodes;
     lds_vu32* lslot = (lds_vu32*)lds.leaf_slot;
     lds_vu32* lcount = (lds_vu32*)lds.leaf_count;
