@@ -87,6 +87,19 @@ def test_trace_any(rt, orc, scenes, scene):
         assert 0 < ref.sum() < ref.size
 
 
+def test_division_fast_paths_are_exact():
+    """rt_math.h replaces IEEE divisions by the division's own refinement chain where the operands are in range.
+    tools/rcp_check (built by `make rcp_check`) compares, on the GPU, the reciprocal with 1.0f / d for every float of
+    the range and the quotient with n / d for 2^35 operand pairs; any difference makes it exit non-zero."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rcp_check")
+    assert os.path.exists(exe), "build it with `make -C raytracer_amd/csrc rcp_check` (__graft_entry__.build() does)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 differ from 1.0f / d" in r.stdout and "0 differ from n / d" in r.stdout, r.stdout
+
+
 def test_task_pool_under_capacity_pressure(rt, scenes, monkeypatch, tmp_path):
     """The task-pool traversal bounds its LDS pool: a step takes fewer tasks when the pool is nearly full and a single
     one beyond the soft limit.  The product's capacities rarely get there, so a variant of the library built with tiny
