@@ -13,12 +13,14 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
         for (int u = 0; u < 8; ++u) {
             if (MODE == 0) {  // f32 mul/add
                 x0 = x0 * a; x1 = x1 + b; x2 = x2 * a; x3 = x3 + b; x4 = x4 * a; x5 = x5 + b; x6 = x6 * a; x7 = x7 + b;
-            } else if (MODE == 1) {  // integer add / xor / shift
-                u0 = u0 + ua; u1 = u1 ^ ub; u2 = u2 >> 1; u3 = u3 + ua; u4 = u4 ^ ub; u5 = (u5 << 1) | 1u; u6 = u6 + ua; u7 = u7 ^ ub;
-            } else if (MODE == 2) {  // 32-bit integer multiply
-                u0 = u0 * ua; u1 = u1 * ub; u2 = u2 * ua; u3 = u3 * ub; u4 = u4 * ua; u5 = u5 * ub; u6 = u6 * ua; u7 = u7 * ub;
-            } else if (MODE == 3) {  // v_max / v_min
-                x0 = fmaxf(x0, a); x1 = fminf(x1, b); x2 = fmaxf(x2, a); x3 = fminf(x3, b); x4 = fmaxf(x4, a); x5 = fminf(x5, b); x6 = fmaxf(x6, a); x7 = fminf(x7, b);
+            } else if (MODE == 1) {  // integer xor with a shifted copy (2 instructions each; chains the compiler cannot fold)
+                u0 ^= u0 >> 15; u1 ^= u1 >> 13; u2 ^= u2 << 7; u3 ^= u3 >> 11; u4 ^= u4 << 5; u5 ^= u5 >> 9; u6 ^= u6 << 3; u7 ^= u7 >> 17;
+            } else if (MODE == 2) {  // 32-bit integer multiply by an odd constant + xor-shift (3 instructions each)
+                u0 = u0 * ua; u0 ^= u0 >> 15; u1 = u1 * ub; u1 ^= u1 >> 15; u2 = u2 * ua; u2 ^= u2 >> 15; u3 = u3 * ub; u3 ^= u3 >> 15;
+                u4 = u4 * ua; u4 ^= u4 >> 15; u5 = u5 * ub; u5 ^= u5 >> 15; u6 = u6 * ua; u6 ^= u6 >> 15; u7 = u7 * ub; u7 ^= u7 >> 15;
+            } else if (MODE == 3) {  // v_max / v_min against a moving operand
+                x0 = fmaxf(x0, x1 * a); x1 = fminf(x1, x2 * b); x2 = fmaxf(x2, x3 * a); x3 = fminf(x3, x4 * b);
+                x4 = fmaxf(x4, x5 * a); x5 = fminf(x5, x6 * b); x6 = fmaxf(x6, x7 * a); x7 = fminf(x7, x0 * b);
             } else if (MODE == 4) {  // rcp
                 x0 = __builtin_amdgcn_rcpf(x0); x1 = __builtin_amdgcn_rcpf(x1); x2 = __builtin_amdgcn_rcpf(x2); x3 = __builtin_amdgcn_rcpf(x3);
                 x4 = __builtin_amdgcn_rcpf(x4); x5 = __builtin_amdgcn_rcpf(x5); x6 = __builtin_amdgcn_rcpf(x6); x7 = __builtin_amdgcn_rcpf(x7);
@@ -60,9 +62,9 @@ void run(const char* name, int ops_per_iter) {
 
 int main() {
     run<0>("f32 mul/add", 64);
-    run<1>("int add/xor/shift", 64);
-    run<2>("int mul 32", 64);
-    run<3>("f32 max/min", 64);
+    run<1>("int shift + xor (2 inst)", 64);
+    run<2>("int mul32 + shift + xor (3 inst)", 64);
+    run<3>("f32 mul + max/min (2 inst)", 64);
     run<4>("rcp", 64);
     run<5>("compare+select (2 inst)", 64);
     run<6>("IEEE f32 division", 64);
