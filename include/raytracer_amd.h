@@ -101,14 +101,31 @@ typedef struct rt_tree_stats {
 } rt_tree_stats;
 int rt_ads_tree_stats(const rt_ads* ads, rt_tree_stats* out);
 
-/* Query counters, as printed by Octree::PrintStats (octree.cc:218-223); they accumulate
- * over every query call on the handle until reset. */
+/* Query counters, as printed by Octree::PrintStats (octree.cc:218-223) and by Renderer::RenderScene
+ * ("Ray-triangle collision count", renderer.cc:60); they accumulate over every query call on the handle
+ * until reset.  search_calls, closest_rays and any_rays are always counted.  The other counters follow the
+ * reference's definitions exactly -- nodes and leaves taken from Search's queue (octree.cc:185-187), candidates
+ * returned (octree.cc:204), ray/triangle tests of the loops over the candidates in list order up to the any-hit
+ * loop's early return (renderer.cc:137,305,311), slab tests (collision_ray_aabb calls, octree.cc:195) -- which the
+ * fast kernels do not visit in that order: rt_ads_search always counts them (it walks breadth-first like the
+ * reference); the trace and render calls count them only while rt_ads_collect_search_stats is on, through an
+ * additional instrumented pass over the same rays.  counted_rays = the queries those counters cover. */
 typedef struct rt_query_stats {
     uint64_t search_calls;     /* "Search method call count": one per ray */
     uint64_t closest_rays, any_rays;
+    uint64_t search_node_count;      /* "Search node count" */
+    uint64_t search_return_count;    /* "Search return count" */
+    uint64_t search_leaves_visited;  /* "Search leaves visited" */
+    uint64_t ray_triangle_tests;     /* "Ray-triangle collision count" */
+    uint64_t slab_tests;
+    uint64_t counted_rays;
+    double search_seconds;           /* "Search time": device time of the traversal kernels (rt_render) or wall time of the call */
 } rt_query_stats;
 int rt_ads_query_stats(const rt_ads* ads, rt_query_stats* out);
 int rt_ads_reset_query_stats(rt_ads* ads);
+/* on != 0: rt_ads_trace_closest, rt_ads_trace_any, rt_render and rt_render_primary_hits also run the instrumented
+ * pass that fills the reference-defined counters of rt_query_stats (slower; results are unchanged). */
+int rt_ads_collect_search_stats(rt_ads* ads, int on);
 
 /* Ads::Search (src/ADS/ads.h:22, src/ADS/Octree/octree.cc:173-207) for a batch of rays.
  * For ray i the candidate triangle indices, in exactly the reference's order (leaves in breadth-first

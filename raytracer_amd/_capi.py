@@ -33,7 +33,10 @@ class TreeStats(C.Structure):
 
 
 class QueryStats(C.Structure):
-    _fields_ = [("search_calls", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64)]
+    _fields_ = [("search_calls", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64),
+                ("search_node_count", C.c_uint64), ("search_return_count", C.c_uint64), ("search_leaves_visited", C.c_uint64),
+                ("ray_triangle_tests", C.c_uint64), ("slab_tests", C.c_uint64), ("counted_rays", C.c_uint64),
+                ("search_seconds", C.c_double)]
 
 
 class RenderConfig(C.Structure):
@@ -64,7 +67,7 @@ class RenderStats(C.Structure):
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
     "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_stats",
-    "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_search", "rt_ads_trace_closest", "rt_ads_trace_any",
+    "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_trace_closest", "rt_ads_trace_any",
     "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
     "rt_host_tree_export_flat", "rt_host_tree_stats",
@@ -100,6 +103,7 @@ def lib():
     L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
     L.rt_ads_reset_query_stats.argtypes = [vp]
+    L.rt_ads_collect_search_stats.argtypes = [vp, C.c_int]
     L.rt_ads_search.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rt_ads_trace_closest.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
     L.rt_ads_trace_any.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp]

@@ -91,7 +91,8 @@ class GpuOctree(Ads):
         return self.search_batch(np.asarray(ray, np.float32).reshape(1, 6))[0]
 
     def PrintStats(self, os):
-        """octree.cc:209-224 (the timing line is omitted: queries are batched on the device)."""
+        """octree.cc:209-224, line for line.  The four Search counters after the call count are exact for Search()
+        itself; for the batched trace / render calls they are collected while collect_search_stats(True) is on."""
         t, q = self.tree_stats(), self.query_stats()
         os.write("Octree stats: \n")
         os.write(f"  Max depth: {t['max_depth']}\n")
@@ -101,6 +102,12 @@ class GpuOctree(Ads):
         os.write(f"  Max triangles in leaf nodes: {t['max_triangles_in_leaf']}\n")
         os.write(f"  Average triangles in leaf nodes: {t['avg_triangles_in_leaf']:g}\n")
         os.write(f"  Search method call count: {q['search_calls']}\n")
+        os.write(f"  Search node count: {q['search_node_count']}\n")
+        os.write(f"  Search time: {q['search_seconds']:g} s\n")
+        os.write(f"  Search return count: {q['search_return_count']}\n")
+        avg = q['search_return_count'] / q['search_calls'] if q['search_calls'] else float('nan')
+        os.write(f"  Average search return count: {avg:g}\n")
+        os.write(f"  Search leaves visited: {q['search_leaves_visited']}\n")
 
     # ---- batched queries -----------------------------------------------------------------------------------------
     def search_batch(self, rays, cap=None):
@@ -183,6 +190,14 @@ class GpuOctree(Ads):
         st = _capi.TreeStats()
         _capi.check(_capi.lib().rt_ads_tree_stats(self._h, C.byref(st)))
         return {n: getattr(st, n) for n, _ in st._fields_}
+
+    def collect_search_stats(self, on=True):
+        """Also run the instrumented pass that counts nodes / leaves / candidates / ray-triangle tests in the
+        reference's definitions (octree.cc:185-187,204; renderer.cc:137,305,311) for trace and render calls."""
+        _capi.check(_capi.lib().rt_ads_collect_search_stats(self._h, int(bool(on))))
+
+    def reset_query_stats(self):
+        _capi.check(_capi.lib().rt_ads_reset_query_stats(self._h))
 
     def query_stats(self):
         st = _capi.QueryStats()

@@ -100,6 +100,21 @@ struct Level {
     }
 };
 
+// Workspace of rt_ads_search: owned by the handle, grow-only.
+struct SearchWork {
+    DevBuf<float> rays;
+    DevBuf<uint32_t> queue, out;
+    DevBuf<uint64_t> counts, offs;
+    DevBuf<unsigned long long> stats;
+    unsigned long long* h_stats = nullptr;  // pinned
+    std::vector<uint32_t> host;
+    void release() {
+        rays.release(); queue.release(); out.release(); counts.release(); offs.release(); stats.release();
+        if (h_stats) (void)hipHostFree(h_stats);
+        h_stats = nullptr;
+    }
+};
+
 constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 
@@ -162,9 +177,13 @@ struct rt_ads {
     uint32_t* h_counters = nullptr;
     DevBuf<float> d_accum, d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
+    SearchWork search;
     hipEvent_t ev[2 + 6 * kMaxTimed] = {};
     bool events_ready = false;
     rt_query_stats q{};
+    bool collect_stats = false;  // run the instrumented pass for the reference-defined counters of rt_query_stats
+    DevBuf<unsigned long long> d_qstats;      // QS_WORDS totals of the instrumented pass
+    unsigned long long* h_qstats = nullptr;   // pinned
 };
 
 namespace {
@@ -240,6 +259,25 @@ uint64_t mode_threads(int, uint64_t n_rays, uint32_t sparse = 0) {
 
 int use_device(const rt_ads* a) {
     HIP_TRY(hipSetDevice(a->device));
+    return RT_OK;
+}
+
+// The instrumented pass (rt_stats.h): zero the totals before the kernels of a call, fetch and accumulate them after.
+int stats_begin(rt_ads* a, hipStream_t stream) {
+    HIP_TRY(a->d_qstats.reserve(QS_WORDS));
+    if (!a->h_qstats) HIP_TRY(hipHostMalloc((void**)&a->h_qstats, QS_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(a->d_qstats.p, 0, QS_WORDS * sizeof(unsigned long long), stream));
+    return RT_OK;
+}
+int stats_end(rt_ads* a, hipStream_t stream) {  // synchronises the stream
+    HIP_TRY(hipMemcpyAsync(a->h_qstats, a->d_qstats.p, QS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    a->q.search_node_count += a->h_qstats[QS_NODES];
+    a->q.search_leaves_visited += a->h_qstats[QS_LEAVES];
+    a->q.search_return_count += a->h_qstats[QS_RETURNED];
+    a->q.slab_tests += a->h_qstats[QS_SLAB];
+    a->q.ray_triangle_tests += a->h_qstats[QS_TRI];
+    a->q.counted_rays += a->h_qstats[QS_RAYS];
     return RT_OK;
 }
 
@@ -419,6 +457,9 @@ void rt_ads_destroy(rt_ads* a) {
     a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
     for (auto& l : a->levels) l.release();
+    a->search.release();
+    a->d_qstats.release();
+    if (a->h_qstats) (void)hipHostFree(a->h_qstats);
     if (a->h_counters) (void)hipHostFree(a->h_counters);
     if (a->events_ready)
         for (auto& e : a->ev) (void)hipEventDestroy(e);
@@ -750,6 +791,11 @@ int rt_ads_reset_query_stats(rt_ads* a) {
     a->q = rt_query_stats{};
     return RT_OK;
 }
+int rt_ads_collect_search_stats(rt_ads* a, int on) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    a->collect_stats = on != 0;
+    return RT_OK;
+}
 
 int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap, uint64_t* out_total) {
     if (!a || (!rays && n) || !out_offsets || !out_total) return fail(RT_ERR_INVALID, "null argument");
@@ -759,59 +805,109 @@ int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offset
     *out_total = 0;
     if (n == 0) return RT_OK;
     if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
-    // A ray can enqueue every node once; chunk the batch so that the queues fit a bounded workspace.
+    // A ray can enqueue every node once; chunk the batch so that the queues fit a bounded workspace.  The workspace
+    // belongs to the handle and only grows: a renderer that calls Search ray by ray allocates on its first call only.
     const uint64_t queue_cap = std::max<uint64_t>(a->n_tree_nodes, 1);
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / (queue_cap * 8)));
-    DevBuf<float> d_rays;
-    DevBuf<uint32_t> d_queue, d_out;
-    DevBuf<uint64_t> d_counts, d_offs;
-    auto cleanup = [&] { d_rays.release(); d_queue.release(); d_out.release(); d_counts.release(); d_offs.release(); };
-    std::vector<uint64_t> counts(n);
+    SearchWork& ws = a->search;
     const DevOctree T = dev_tree(a);
-    hipError_t e;
-#define SEARCH_TRY(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
-    SEARCH_TRY(d_rays.reserve(chunk * 6));
-    SEARCH_TRY(d_queue.reserve(chunk * queue_cap * 2));
-    SEARCH_TRY(d_counts.reserve(chunk));
-    SEARCH_TRY(d_offs.reserve(chunk));
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            uint64_t total = 0;
-            for (uint64_t i = 0; i < n; ++i) {
-                out_offsets[i] = total;
-                total += counts[i];
-            }
-            out_offsets[n] = total;
-            *out_total = total;
-            if (total > cap || (!out_tri && total)) { cleanup(); return fail(RT_ERR_CAPACITY, "candidate buffer too small: need %llu entries", (unsigned long long)total); }
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIP_TRY(ws.rays.reserve(chunk * 6));
+    HIP_TRY(ws.queue.reserve(chunk * queue_cap * 2));
+    HIP_TRY(ws.stats.reserve(2));
+    if (!ws.h_stats) HIP_TRY(hipHostMalloc((void**)&ws.h_stats, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ws.stats.p, 0, 2 * sizeof(unsigned long long), 0));
+    uint64_t returned = 0;
+
+    // Small batches (the drop-in Ads::Search sends one ray per call): one launch writes every ray's list into a region
+    // of its own together with the list's length, one copy brings both back.  A list longer than its region falls
+    // through to the exact two-pass form below.
+    constexpr uint64_t kRegion = 1024, kSmallBatch = 64;
+    bool done = false;
+    if (n <= kSmallBatch) {
+        const uint32_t m = (uint32_t)n;
+        const size_t words = (size_t)m * 2 + (size_t)m * kRegion;  // m 64-bit counts, then m regions
+        HIP_TRY(ws.out.reserve(words));
+        ws.host.resize(words);
+        HIP_TRY(hipMemcpyAsync(ws.rays.p, rays, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(k_search<true>, dim3((m + 63) / 64), dim3(64), 0, 0, T, ws.rays.p, m, ws.queue.p, (uint32_t)queue_cap,
+                           (uint64_t*)ws.out.p, (const uint64_t*)nullptr, ws.out.p + (size_t)m * 2, (uint64_t)0, kRegion, ws.stats.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ws.host.data(), ws.out.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, 0));
+        HIP_TRY(hipMemcpyAsync(ws.h_stats, ws.stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, 0));
+        HIP_TRY(hipStreamSynchronize(0));
+        const uint64_t* counts = reinterpret_cast<const uint64_t*>(ws.host.data());
+        bool fits = true;
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            if (counts[i] == ~0ull) return fail(RT_ERR_CAPACITY, "search queue overflow");
+            fits = fits && counts[i] <= kRegion;
+            out_offsets[i] = total;
+            total += counts[i];
         }
-        for (uint64_t b = 0; b < n; b += chunk) {
-            const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
-            SEARCH_TRY(hipMemcpy(d_rays.p, rays + b * 6, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice));
-            const dim3 grid((m + 63) / 64), block(64);
-            if (pass == 0) {
-                hipLaunchKernelGGL(k_search<false>, grid, block, 0, 0, T, d_rays.p, m, d_queue.p, (uint32_t)queue_cap, d_counts.p, nullptr, nullptr);
-                SEARCH_TRY(hipGetLastError());
-                SEARCH_TRY(hipMemcpy(counts.data() + b, d_counts.p, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-                for (uint32_t i = 0; i < m; ++i)
-                    if (counts[b + i] == ~0ull) { cleanup(); return fail(RT_ERR_HIP, "search queue overflow"); }
-            } else {
-                std::vector<uint64_t> rel(m);
-                const uint64_t base = out_offsets[b];
-                for (uint32_t i = 0; i < m; ++i) rel[i] = out_offsets[b + i] - base;
-                const uint64_t chunk_total = out_offsets[b + m] - base;
-                if (chunk_total == 0) continue;
-                SEARCH_TRY(d_out.reserve(chunk_total));
-                SEARCH_TRY(hipMemcpy(d_offs.p, rel.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(k_search<true>, grid, block, 0, 0, T, d_rays.p, m, d_queue.p, (uint32_t)queue_cap, nullptr, d_offs.p, d_out.p);
-                SEARCH_TRY(hipGetLastError());
-                SEARCH_TRY(hipMemcpy(out_tri + base, d_out.p, chunk_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            }
+        out_offsets[m] = total;
+        *out_total = total;
+        if (total > cap || (!out_tri && total)) return fail(RT_ERR_CAPACITY, "candidate buffer too small: need %llu entries", (unsigned long long)total);
+        if (fits) {
+            for (uint32_t i = 0; i < m; ++i)
+                if (counts[i]) memcpy(out_tri + out_offsets[i], ws.host.data() + (size_t)m * 2 + (size_t)i * kRegion, counts[i] * sizeof(uint32_t));
+            returned = total;
+            done = true;
+        } else {
+            HIP_TRY(hipMemsetAsync(ws.stats.p, 0, 2 * sizeof(unsigned long long), 0));  // the two-pass form counts again
         }
     }
-#undef SEARCH_TRY
-    cleanup();
+    if (!done) {
+        std::vector<uint64_t> counts(n);
+        HIP_TRY(ws.counts.reserve(chunk));
+        HIP_TRY(ws.offs.reserve(chunk));
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                uint64_t total = 0;
+                for (uint64_t i = 0; i < n; ++i) {
+                    out_offsets[i] = total;
+                    total += counts[i];
+                }
+                out_offsets[n] = total;
+                *out_total = total;
+                if (total > cap || (!out_tri && total)) return fail(RT_ERR_CAPACITY, "candidate buffer too small: need %llu entries", (unsigned long long)total);
+                returned = total;
+            }
+            for (uint64_t b = 0; b < n; b += chunk) {
+                const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
+                HIP_TRY(hipMemcpy(ws.rays.p, rays + b * 6, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice));
+                const dim3 grid((m + 63) / 64), block(64);
+                if (pass == 0) {
+                    hipLaunchKernelGGL(k_search<false>, grid, block, 0, 0, T, ws.rays.p, m, ws.queue.p, (uint32_t)queue_cap, ws.counts.p,
+                                       (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (uint64_t)0, ws.stats.p);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpy(counts.data() + b, ws.counts.p, (size_t)m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < m; ++i)
+                        if (counts[b + i] == ~0ull) return fail(RT_ERR_CAPACITY, "search queue overflow");
+                } else {
+                    std::vector<uint64_t> rel(m);
+                    const uint64_t base = out_offsets[b];
+                    for (uint32_t i = 0; i < m; ++i) rel[i] = out_offsets[b + i] - base;
+                    const uint64_t chunk_total = out_offsets[b + m] - base;
+                    if (chunk_total == 0) continue;
+                    HIP_TRY(ws.out.reserve(chunk_total));
+                    HIP_TRY(hipMemcpy(ws.offs.p, rel.data(), (size_t)m * sizeof(uint64_t), hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(k_search<true>, grid, block, 0, 0, T, ws.rays.p, m, ws.queue.p, (uint32_t)queue_cap, (uint64_t*)nullptr,
+                                       ws.offs.p, ws.out.p, chunk_total, (uint64_t)0, (unsigned long long*)nullptr);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpy(out_tri + base, ws.out.p, chunk_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                }
+            }
+        }
+        HIP_TRY(hipMemcpy(ws.h_stats, ws.stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    // octree.cc:174,185-187,204
     a->q.search_calls += n;
+    a->q.search_node_count += ws.h_stats[0];
+    a->q.search_leaves_visited += ws.h_stats[1];
+    a->q.search_return_count += returned;
+    a->q.counted_rays += n;
+    a->q.search_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return RT_OK;
 }
 
@@ -844,6 +940,14 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
     RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, sparse);
     HIP_TRY(hipGetLastError());
+    if (a->collect_stats) {
+        if (int rc = stats_begin(a, stream)) return rc;
+        const dim3 sgrid((unsigned)((n + 255) / 256));
+        if (cull) hipLaunchKernelGGL((k_stats_rays<false, true>), sgrid, block, 0, stream, dev_tree(a), d_o, d_d, n, a->d_qstats.p);
+        else hipLaunchKernelGGL((k_stats_rays<false, false>), sgrid, block, 0, stream, dev_tree(a), d_o, d_d, n, a->d_qstats.p);
+        HIP_TRY(hipGetLastError());
+        if (int rc = stats_end(a, stream)) return rc;
+    }
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(out_tri, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -880,6 +984,14 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
     RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
     HIP_TRY(hipGetLastError());
+    if (a->collect_stats) {
+        if (int rc = stats_begin(a, stream)) return rc;
+        const dim3 sgrid((unsigned)((n + 255) / 256));
+        if (cull) hipLaunchKernelGGL((k_stats_rays<true, true>), sgrid, block, 0, stream, dev_tree(a), d_p, d_l, n, a->d_qstats.p);
+        else hipLaunchKernelGGL((k_stats_rays<true, false>), sgrid, block, 0, stream, dev_tree(a), d_p, d_l, n, a->d_qstats.p);
+        HIP_TRY(hipGetLastError());
+        if (int rc = stats_end(a, stream)) return rc;
+    }
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1079,6 +1191,9 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     hipEvent_t* ev_shadow = a->ev + 2 + 4 * kMaxTimed;
     HIP_TRY(hipEventRecord(ev_total[0], stream));
     const dim3 block(256);
+    if (a->collect_stats) {
+        if (int rc = stats_begin(a, stream)) return rc;
+    }
     for (int s = 0; s < c->samples_per_pixel && n0 > 0; ++s) {
         F.spp_sample = (uint32_t)s;
         HIP_TRY(hipMemsetAsync(a->d_counters.p, 0, (size_t)max_levels * CNT_WORDS * sizeof(uint32_t), stream));
@@ -1101,6 +1216,12 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 ++n_timed_closest;
             }
             st.launches_closest++;
+            if (a->collect_stats) {
+                const dim3 sgrid((n + 255) / 256);
+                if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, a->d_qstats.p);
+                else hipLaunchKernelGGL(k_stats_closest<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, a->d_qstats.p);
+                HIP_TRY(hipGetLastError());
+            }
             if (L == 0) st.primary_rays += 0;  // counted below from the valid pixel count
             else st.secondary_rays += n;
             if (timed_c) st.timed_closest_rays += L == 0 ? valid_pixels : n;
@@ -1153,6 +1274,14 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                     ++n_timed_shadow;
                 }
                 st.launches_shadow++;
+                if (a->collect_stats) {
+                    const uint64_t threads = (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle;
+                    if (threads > 0x7fffffffull * 256ull) return fail(RT_ERR_UNSUPPORTED, "level too large for the instrumented pass");
+                    const dim3 sgrid((uint32_t)((threads + 255) / 256));
+                    if (F.cull) hipLaunchKernelGGL(k_stats_shadow<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
+                    else hipLaunchKernelGGL(k_stats_shadow<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
+                    HIP_TRY(hipGetLastError());
+                }
             }
             const bool timed_s = n_timed_shade < kMaxTimed;
             if (timed_s) { HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade], stream)); }
@@ -1200,6 +1329,9 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         }
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (a->collect_stats) {
+        if (int rc = stats_end(a, stream)) return rc;
+    }
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_total[0], ev_total[1]));
     st.ms_total = ms;
@@ -1219,6 +1351,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     a->q.search_calls += st.rays;
     a->q.closest_rays += st.primary_rays + st.secondary_rays;
     a->q.any_rays += st.shadow_rays;
+    a->q.search_seconds += ((double)st.ms_closest + (double)st.ms_shadow) * 1e-3;
     if (stats) *stats = st;
     return RT_OK;
 }
@@ -1256,6 +1389,14 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());
+    if (a->collect_stats) {
+        const SceneDev S = scene_dev(a);
+        if (int rc = stats_begin(a, stream)) return rc;
+        if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, a->d_qstats.p);
+        else hipLaunchKernelGGL(k_stats_closest<false>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, a->d_qstats.p);
+        HIP_TRY(hipGetLastError());
+        if (int rc = stats_end(a, stream)) return rc;
+    }
     if (mem == RT_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_t, d_t, npix * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(out_tri, d_tri, npix * 4, hipMemcpyDeviceToHost, stream));

@@ -21,6 +21,7 @@
 #include "rt_traverse.h"
 #include "rt_traverse_lane.h"
 #include "rt_traverse_pool.h"
+#include "rt_stats.h"
 
 namespace rt {
 
@@ -251,6 +252,28 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
+// The instrumented pass over the same caller-supplied rays (rt_stats.h): ANY -> second = light points.
+template <bool ANY, bool CULL>
+__global__ void __launch_bounds__(256) k_stats_rays(DevOctree T, const float* __restrict__ first, const float* __restrict__ second, uint64_t n,
+                                                    unsigned long long* __restrict__ totals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    float t_limit = 0.0f;
+    if (valid) {
+        o = mk(first[i * 3], first[i * 3 + 1], first[i * 3 + 2]);
+        d = mk(second[i * 3], second[i * 3 + 1], second[i * 3 + 2]);
+    }
+    if (ANY) {  // renderer.cc:289-290
+        const f3 pl = d - o;
+        t_limit = length(pl);
+        d = normalize(pl);
+    }
+    RayCounters c;
+    stats_ray<ANY, CULL>(T, valid, o, d, t_limit, c);
+    stats_flush(c, totals);
+}
+
 // ---- renderer level kernels ------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __restrict__ rays, uint32_t level, uint32_t i, uint32_t n,
@@ -409,6 +432,61 @@ __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F
         if (lit && writer && word < words)
             vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
     }
+}
+
+// The instrumented passes of a level (rt_stats.h): the same rays k_closest / k_shadow trace, one ray per thread.
+template <bool CULL>
+__global__ void __launch_bounds__(256) k_stats_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                                       unsigned long long* __restrict__ totals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, n, valid, o, d, pixel, node_id);
+    RayCounters c;
+    stats_ray<false, CULL>(S.tree, valid, o, d, 0.0f, c);
+    stats_flush(c, totals);
+}
+
+// Thread g handles shadow ray q = g % per_hit of hit j = g / per_hit, q = light * spt + sample.
+template <bool CULL>
+__global__ void __launch_bounds__(256) k_stats_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                                      const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
+                                                      const uint32_t* __restrict__ work, const uint32_t* __restrict__ counters,
+                                                      unsigned long long* __restrict__ totals) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_hit = S.n_lights * (uint32_t)F.spt;
+    const uint32_t n_work = counters[CNT_WORK];
+    const uint64_t j64 = g / per_hit;
+    const bool active = j64 < n_work;
+    const uint32_t q = (uint32_t)(g % per_hit);
+    const uint32_t l = q / (uint32_t)F.spt, smp = q % (uint32_t)F.spt;
+    uint32_t i = 0;
+    if (active) i = work[j64];
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
+    valid = valid && active;
+    float t = 0.0f;
+    int32_t light_eq = -1;
+    if (valid) {
+        t = hit_t[i];
+        light_eq = S.tri_shade[hit_tri[i]].light_eq;
+    }
+    const f3 P = o + (d * t);  // renderer.cc:146
+    const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
+    // renderer.cc:212-214: the light loop ends at the light the hit triangle itself is
+    const uint32_t lights_traced = !valid ? 0u : ((light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights);
+    const bool on = l < lights_traced;
+    const LightDev& L = S.lights[on ? l : 0u];
+    const f3 p_l = light_sample(L, pre, l, smp);
+    const f3 to_l = p_l - P;  // renderer.cc:289-290
+    const float dist = length(to_l);
+    const f3 d_l = normalize(to_l);
+    RayCounters c;
+    stats_ray<true, CULL>(S.tree, on, P, d_l, dist, c);
+    stats_flush(c, totals);
 }
 
 // Local illumination + recursion gate + secondary ray construction for every hit of one level
@@ -602,48 +680,77 @@ __global__ void __launch_bounds__(256) k_primary_hits(FrameParams F, const float
 }
 
 // ---- Ads::Search restated (octree.cc:173-207): breadth-first, one ray per thread, queue in a workspace ---------------
+//
+// FILL = false: counts[i] = the length of ray i's candidate list (octree.cc:204).  FILL = true: the list itself, written
+// to out_tri from position offsets[i] (stride == 0) or i * stride (stride != 0: every ray owns a region of `stride`
+// entries and counts[i] is written as well, so that one launch serves callers that accept a retry when a list is
+// longer than its region).  Entries at or beyond `limit` (stride == 0) / beyond the ray's region are not written.
+// `stats`, if not null, receives the sums over the launch of nodes taken from the queue and of leaves among them
+// (search_node_count_ and search_leaves_visited_, octree.cc:185-187), one 64-bit atomic each per wave.
 
 template <bool FILL>
 __global__ void __launch_bounds__(64) k_search(DevOctree T, const float* __restrict__ rays, uint32_t n, uint32_t* __restrict__ queue,
                                                uint32_t queue_cap, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
-                                               uint32_t* __restrict__ out_tri) {
+                                               uint32_t* __restrict__ out_tri, uint64_t limit, uint64_t stride,
+                                               unsigned long long* __restrict__ stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const f3 o = mk(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
-    const f3 d = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t* q = queue + (size_t)i * queue_cap * 2;
-    uint64_t total = 0;
-    uint64_t w = FILL ? offsets[i] : 0;
-    uint32_t qh = 0, qt = 0;
-    if (T.root_info1 != 0) {
-        q[0] = T.root_info0;
-        q[1] = T.root_info1;
-        qt = 1;
-    }
-    while (qh < qt) {
-        const uint32_t i0 = q[qh * 2], i1 = q[qh * 2 + 1];
-        ++qh;
-        if (!(i1 & kChildInternal)) {
-            if (FILL)
-                for (uint32_t k = 0; k < i1; ++k) out_tri[w + k] = T.slots[i0 + k].tri;
-            w += i1;
-            total += i1;
-            continue;
+    uint32_t nodes_taken = 0, leaves_taken = 0;
+    if (i < n) {
+        const f3 o = mk(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+        const f3 d = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+        const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        uint32_t* q = queue + (size_t)i * queue_cap * 2;
+        uint64_t total = 0;
+        uint64_t w = 0, lim = 0;
+        if (FILL) {
+            w = stride ? (uint64_t)i * stride : offsets[i];
+            lim = stride ? w + stride : limit;
         }
-        const NodeRec& r = T.nodes[i0];
-        for (int c = 0; c < 8; ++c) {
-            if (r.info[c][1] == 0) continue;
-            const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-            if (!ray_box(o, inv, r.lo[0][bx], r.lo[1][by], r.lo[2][bz], r.hi[0][bx], r.hi[1][by], r.hi[2][bz])) continue;
-            if (qt < queue_cap) {
-                q[qt * 2] = r.info[c][0];
-                q[qt * 2 + 1] = r.info[c][1];
+        uint32_t qh = 0, qt = 0;
+        if (T.root_info1 != 0) {
+            q[0] = T.root_info0;
+            q[1] = T.root_info1;
+            qt = 1;
+        }
+        while (qh < qt && qh < queue_cap) {
+            const uint32_t i0 = q[qh * 2], i1 = q[qh * 2 + 1];
+            ++qh;
+            ++nodes_taken;
+            if (!(i1 & kChildInternal)) {
+                ++leaves_taken;
+                if (FILL)
+                    for (uint32_t k = 0; k < i1; ++k)
+                        if (w + k < lim) out_tri[w + k] = T.slots[i0 + k].tri;
+                w += i1;
+                total += i1;
+                continue;
             }
-            ++qt;
+            const NodeRec& r = T.nodes[i0];
+            for (int c = 0; c < 8; ++c) {
+                if (r.info[c][1] == 0) continue;
+                const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+                if (!ray_box(o, inv, r.lo[0][bx], r.lo[1][by], r.lo[2][bz], r.hi[0][bx], r.hi[1][by], r.hi[2][bz])) continue;
+                if (qt < queue_cap) {
+                    q[qt * 2] = r.info[c][0];
+                    q[qt * 2 + 1] = r.info[c][1];
+                }
+                ++qt;
+            }
+        }
+        if (!FILL || stride) counts[i] = (qt > queue_cap) ? ~0ull : total;
+    }
+    if (stats) {
+        uint32_t a = nodes_taken, b = leaves_taken;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            a += __shfl_xor(a, s, 64);
+            b += __shfl_xor(b, s, 64);
+        }
+        if (__lane_id() == 0 && a) {
+            atomicAdd(&stats[0], (unsigned long long)a);
+            atomicAdd(&stats[1], (unsigned long long)b);
         }
     }
-    if (!FILL) counts[i] = (qt > queue_cap) ? ~0ull : total;
 }
 
 }  // namespace rt

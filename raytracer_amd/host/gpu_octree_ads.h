@@ -91,7 +91,20 @@ class GpuOctree : public Ads {
         os << "  Max triangles in leaf nodes: " << t.max_triangles_in_leaf << "\n";
         os << "  Average triangles in leaf nodes: " << t.avg_triangles_in_leaf << "\n";
         os << "  Search method call count: " << q.search_calls << "\n";
+        os << "  Search node count: " << q.search_node_count << "\n";
+        os << "  Search time: " << (float)q.search_seconds << " s" << "\n";
+        os << "  Search return count: " << q.search_return_count << "\n";
+        os << "  Average search return count: " << (float)q.search_return_count / q.search_calls << "\n";
+        os << "  Search leaves visited: " << q.search_leaves_visited << "\n";
     }
+    // Renderer::RenderScene prints this one itself (renderer.cc:60); a renderer on top of the batched calls reads it here.
+    uint64_t RayTriangleCollisionCount() const {
+        rt_query_stats q{};
+        check(rt_ads_query_stats(handle_, &q));
+        return q.ray_triangle_tests;
+    }
+    // The batched calls count nodes / leaves / candidates / triangle tests in the reference's definitions only while this is on.
+    void CollectSearchStats(bool on) { check(rt_ads_collect_search_stats(handle_, on ? 1 : 0)); }
 
     // Batched forms of the renderer's two hot loops (renderer.cc:116-142 and :288-313).  n rays, arrays of
     // 3 floats per ray; results as documented in raytracer_amd.h.

@@ -60,8 +60,9 @@ class Camera:
 
 
 class Renderer:
-    def __init__(self, config, seed=42, device=0, aspect_mode=_capi.RT_ASPECT_COMPAT):
+    def __init__(self, config, seed=42, device=0, aspect_mode=_capi.RT_ASPECT_COMPAT, collect_stats=False):
         self.config_ = config
+        self.collect_stats = bool(collect_stats)  # the reference-defined Search / ray-triangle counters (slower)
         self.seed, self.device, self.aspect_mode = int(seed) & 0xffffffff, device, aspect_mode
         # renderer.cc:339-343 (a missing key raises KeyError like json::at throws)
         self.background_color_ = [float(config["background_color"][i]) for i in range(3)]
@@ -90,6 +91,7 @@ class Renderer:
         ads = self.setup_ads()
         ads.Build(scene.pos)
         ads.set_shading(scene.norm, scene.matid, scene.materials)
+        ads.collect_search_stats(self.collect_stats)
         cfg = make_render_config(camera.pos, camera.up, camera.dir, camera.fov, camera.width, camera.height,
                                  spp=camera.samples_per_pixel, max_depth=self.max_depth_, spt=self.samples_per_triangle_,
                                  render_type=self.render_type_, shading=self.shading_type_, cull=self.cull_backfaces_,
@@ -100,16 +102,8 @@ class Renderer:
         if log is not None:
             ads.PrintStats(log)
             log.write(f"Rendering time: {time.time() - t0:g} s\n")
-            log.write(f"Rays (Search-equivalent queries): {st.rays}\n")
+            q = ads.query_stats()
+            if q["counted_rays"]:
+                log.write(f"Ray-triangle collision count: {q['ray_triangle_tests']}\n")  # renderer.cc:60
         write_ppm(self.config_["output"]["filename"], img)  # renderer.cc:66, 381-390
         return img
-
-
-def main(config):
-    """src/main.cc:22-30 for a parsed config.json."""
-    seed = int(config["seed"])
-    if seed == -1:
-        seed = int(time.time())
-    renderer = Renderer(config["renderer"], seed=seed)
-    scene = load_scene(config["obj_loader"], config["scene"])
-    return renderer.RenderScene(scene, Camera(config["scene"]["camera"]))

@@ -1,0 +1,179 @@
+"""GPU tests of the benchmark configurations at their true parameters.
+
+Each configuration is checked against the oracle at a size the oracle finishes in seconds, and at its full size
+through properties that do not need the oracle for the whole frame: every traversal form renders the same bits, a band
+split over ranks reassembles to the same frame, a band of rows equals the oracle's pixels, the ray count is stable."""
+import numpy as np
+import pytest
+
+from conftest import CAMERAS
+
+pytestmark = pytest.mark.gpu
+
+FORMS = {
+    "auto": {},
+    "general": {"RT_DISABLE_SMALL_TREE": "1"},
+    "lane": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"},
+    "pool": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"},
+}
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    return raytracer_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def build(rt, sc, monkeypatch=None, form="auto", builder="auto"):
+    if monkeypatch is not None:
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in FORMS[form].items():
+            monkeypatch.setenv(k, v)
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10, "builder": builder})
+    g.Build(sc.pos)
+    g.set_shading(sc.norm if getattr(sc, "has_normals", False) else None, sc.matid, sc.materials)
+    return g
+
+
+# ---- Cornell-Original, fuzzysampling 64 samples per pixel, 32 samples per light (renderer.cc:43-49, 202-247) ----------
+
+@pytest.mark.parametrize("w,h,aspect", [(48, 27, 0), (32, 32, 0), (40, 24, 1)])
+def test_original_spp64_spt32_against_the_oracle(rt, orc, scenes, monkeypatch, w, h, aspect):
+    sc = scenes["original"]
+    kw = dict(fov=0.6, width=w, height=h, spp=64, spt=32, render_type="blinn_phong", shading="flat", **CAMERAS["original"])
+    ref, ref_tri, ref_t, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, aspect_mode=aspect, **kw))
+    first = None
+    for form in FORMS:
+        g = build(rt, sc, monkeypatch, form)
+        cfg = rt.make_render_config(aspect_mode=aspect, **kw)
+        img, st = g.render(cfg)
+        t, tri = g.primary_hits(cfg)
+        assert np.array_equal(tri, ref_tri) and np.array_equal(bits(t), bits(ref_t)), form
+        assert (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays) == \
+               (ost.search_calls, ost.primary_rays, ost.secondary_rays, ost.shadow_rays), form
+        assert np.abs(img - ref).max() <= 1.0 / 255.0, form
+        if first is None:
+            first = img
+        assert np.array_equal(bits(img), bits(first)), form  # the forms agree bit for bit
+    assert ost.primary_rays == 64 * w * h and ost.shadow_rays > 30 * ost.primary_rays
+
+
+def test_original_spp64_spt32_full_size_properties(rt, orc, scenes, monkeypatch):
+    """3840x2160 is 39 G rays per frame (1.2 s on one GPU): the full-size check renders one eighth of the bands -- the
+    share of one of 8 ranks -- in two traversal forms and compares a band of it with the oracle."""
+    sc = scenes["original"]
+    kw = dict(fov=0.6, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong", shading="flat", **CAMERAS["original"])
+    out = {}
+    for form in ("auto", "general"):
+        g = build(rt, sc, monkeypatch, form)
+        img = np.zeros((2160, 3840, 3), np.float32)
+        _, st = g.render(rt.make_render_config(band_rank=3, band_world=8, **kw), out=img)
+        out[form] = (img, st.rays, st.shadow_rays)
+    assert np.array_equal(bits(out["auto"][0]), bits(out["general"][0])) and out["auto"][1:] == out["general"][1:]
+    img = out["auto"][0]
+    # band 3 = rows 24..31 belong to rank 3 of 8; rows 0..23 do not and must be untouched
+    assert not img[:24].any() and img[24:32].any()
+    ref, _, _, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(24, 25), **kw), want_hits=False)
+    assert np.abs(img[24] - ref[24]).max() <= 1.0 / 255.0
+    # every pixel sample issues its camera ray; the frame share is 1/8 of the 270 bands (34 bands for rank 3)
+    assert out["auto"][1] > 64 * 3840 * 8 * 33 * 30
+
+
+# ---- Cornell-Sphere, smooth Blinn-Phong, 4 samples per pixel, 32 samples per light, reflection + refraction ------------
+
+@pytest.mark.parametrize("w,h,aspect", [(64, 36, 0), (40, 40, 0), (48, 27, 1)])
+def test_sphere_spp4_spt32_against_the_oracle(rt, orc, scenes, monkeypatch, w, h, aspect):
+    sc = scenes["sphere"]
+    kw = dict(fov=0.6, width=w, height=h, spp=4, spt=32, render_type="blinn_phong", shading="smooth", max_depth=10, **CAMERAS["sphere"])
+    ref, ref_tri, ref_t, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, aspect_mode=aspect, **kw))
+    first = None
+    for form in ("auto", "lane", "pool"):
+        g = build(rt, sc, monkeypatch, form)
+        cfg = rt.make_render_config(aspect_mode=aspect, **kw)
+        img, st = g.render(cfg)
+        t, tri = g.primary_hits(cfg)
+        assert np.array_equal(tri, ref_tri) and np.array_equal(bits(t), bits(ref_t)), form
+        assert (st.rays, st.secondary_rays, st.shadow_rays) == (ost.search_calls, ost.secondary_rays, ost.shadow_rays), form
+        assert np.abs(img - ref).max() <= 1.0 / 255.0, form
+        if first is None:
+            first = img
+        assert np.array_equal(bits(img), bits(first)), form
+    if h >= w or aspect:
+        assert ost.secondary_rays > 0  # reflection / refraction levels occur (in compat aspect with h < w the one scanline may miss the spheres)
+
+
+def test_sphere_spp4_spt32_full_size_properties(rt, orc, scenes, monkeypatch):
+    sc = scenes["sphere"]
+    kw = dict(fov=0.6, width=1920, height=1080, spp=4, spt=32, render_type="blinn_phong", shading="smooth", max_depth=10,
+              **CAMERAS["sphere"])
+    cfg = rt.make_render_config(**kw)
+    g = build(rt, sc, monkeypatch, "auto")
+    full, st = g.render(cfg)
+    again, st2 = g.render(cfg)
+    assert np.array_equal(bits(again), bits(full)) and st2.rays == st.rays
+    assert st.primary_rays == 4 * 1920 * 1080 and st.shadow_rays > 50 * st.primary_rays
+    # rows 536..543 against the oracle
+    ref, _, _, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(536, 544), **kw), want_hits=False)
+    assert np.abs(full[536:544] - ref[536:544]).max() <= 1.0 / 255.0
+    # the per-lane form on the same frame
+    g2 = build(rt, sc, monkeypatch, "lane")
+    img2, s2 = g2.render(cfg)
+    assert np.array_equal(bits(img2), bits(full)) and s2.rays == st.rays
+    # 4 ranks' bands
+    out = np.zeros_like(full)
+    rays = 0
+    for r in range(4):
+        _, sr = g.render(rt.make_render_config(band_rank=r, band_world=4, **kw), out=out)
+        rays += sr.rays
+    assert np.array_equal(bits(out), bits(full)) and rays == st.rays
+    # true aspect: the whole picture (both spheres in view), forms agree, a band equals the oracle
+    cfg_t = rt.make_render_config(aspect_mode=1, **kw)
+    full_t, st_t = g.render(cfg_t)
+    img_t, s_t = g2.render(cfg_t)
+    assert np.array_equal(bits(img_t), bits(full_t)) and s_t.rays == st_t.rays and st_t.secondary_rays > 1000000
+    ref, _, _, _ = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, aspect_mode=1, rows=(700, 702), **kw),
+                              want_hits=False)
+    assert np.abs(full_t[700:702] - ref[700:702]).max() <= 1.0 / 255.0
+
+
+# ---- 1,310,754 triangles, Phong, hard shadows, 3840x2160 ---------------------------------------------------------------
+
+def test_large_tree_4k_frame_properties(rt, orc, monkeypatch):
+    from test_gpu_parity import synthetic_scene
+    s = synthetic_scene(8)
+    kw = dict(fov=0.6, width=3840, height=2160, spt=1, render_type="phong", shading="flat", aspect_mode=1, **CAMERAS["original"])
+    cfg = rt.make_render_config(**kw)
+    frames = {}
+    for form, builder in (("auto", "device"), ("lane", "device"), ("pool", "host")):
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL"):
+            monkeypatch.delenv(k, raising=False)
+        if form != "auto":
+            monkeypatch.setenv("RT_TRAVERSAL", form)
+        g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10, "builder": builder})
+        g.Build(s.pos)
+        g.set_shading(None, s.matid, s.materials)
+        img, st = g.render(cfg)
+        frames[form] = (img, st.rays, st.shadow_rays, st.secondary_rays)
+        if form == "auto":
+            # two ranks' bands reassemble to the same frame
+            out = np.zeros_like(img)
+            rays = 0
+            for r in range(2):
+                _, sr = g.render(rt.make_render_config(band_rank=r, band_world=2, **kw), out=out)
+                rays += sr.rays
+            assert np.array_equal(bits(out), bits(img)) and rays == st.rays
+        g.close()
+    for form in ("lane", "pool"):
+        assert np.array_equal(bits(frames[form][0]), bits(frames["auto"][0])), form
+        assert frames[form][1:] == frames["auto"][1:], form
+    assert frames["auto"][1] > 2 * 3840 * 2160
+    # rows 1000..1001 (through the sphere) against the oracle
+    osc = orc.Scene.from_arrays(s.pos, None, s.matid, s.materials)
+    ref, _, _, ost = orc.render(osc, orc.Octree(osc, 16, 10),
+                                orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(1000, 1002), **{**kw, "aspect_mode": orc.ASPECT_TRUE}), want_hits=False)
+    assert np.abs(frames["auto"][0][1000:1002] - ref[1000:1002]).max() <= 1.0 / 255.0

@@ -442,8 +442,9 @@ def test_against_the_reference_binary_run_live(rt, scenes, case):
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_runner
-    if not ref_runner.available():
-        pytest.skip("oracle/_ref/raytracer_ref has not been built")
+    # the binary is built where the reference checkout exists and travels with the working tree; a GPU run without it
+    # would silently lose the checks against the reference itself
+    assert ref_runner.available(), "oracle/_ref/raytracer_ref is missing: run `make -C oracle ref` where /root/reference exists"
     scene, rtype, shading, cull, w, h, cpos, cdir, fov, (mb, md) = case
     sc = scenes[scene]
     nrm = sc.norm if sc.has_normals else None
@@ -476,8 +477,9 @@ def test_random_triangle_soups_against_the_reference_binary(rt, scenes, seed, n_
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_runner
-    if not ref_runner.available():
-        pytest.skip("oracle/_ref/raytracer_ref has not been built")
+    # the binary is built where the reference checkout exists and travels with the working tree; a GPU run without it
+    # would silently lose the checks against the reference itself
+    assert ref_runner.available(), "oracle/_ref/raytracer_ref is missing: run `make -C oracle ref` where /root/reference exists"
     rs = np.random.RandomState(seed)
     centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
     size = np.exp(rs.uniform(np.log(0.02), np.log(4.0), (n_tri, 1, 1)))
@@ -689,8 +691,7 @@ def test_dropin_behind_reference_ads_interface(scenes, tmp_path):
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "oracle", "_ref", "ads_dropin_test")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/ads_dropin_test not built (no reference checkout at build time)")
+    assert os.path.exists(exe), "oracle/_ref/ads_dropin_test is missing: run `make -C oracle ref` where /root/reference exists"
     for name in ("original", "sphere"):
         raw = tmp_path / f"{name}.raw"
         pos = np.ascontiguousarray(scenes[name].pos, np.float32)
