@@ -135,6 +135,20 @@ int rt_ads_collect_search_stats(rt_ads* ads, int on);
 int rt_ads_search(rt_ads* ads, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap,
                   uint64_t* out_total);
 
+/* rt_ads_search for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  rays (n x 6 floats), out_offsets
+ * (n + 1 entries), out_tri (cap entries) and out_total (1 entry) are DEVICE memory of the handle's device; the call
+ * is asynchronous on `stream` and allocates nothing: the traversal queues and per-ray counts live in a fixed
+ * scratch array inside the library (RT_SEARCH_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends).
+ * Limits: n <= RT_SEARCH_NOALLOC_MAX_RAYS and n * (octree nodes) * 8 bytes <= RT_SEARCH_NOALLOC_SCRATCH_BYTES,
+ * otherwise RT_ERR_CAPACITY and nothing is launched.  *out_total receives the total list length; if it exceeds cap,
+ * the entries at positions >= cap are not written (the caller checks *out_total after synchronising).  All calls on
+ * one GPU share the scratch array: calls that overlap on a GPU (different streams or handles) race. */
+#define RT_SEARCH_NOALLOC_MAX_RAYS 4096u
+#define RT_SEARCH_NOALLOC_SCRATCH_BYTES (16u << 20)
+int rt_ads_search_noalloc(rt_ads* ads, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap,
+                          uint64_t* out_total, void* stream);
+
 /* Ads::Search + the closest-hit loop of Renderer::ray_color (src/Renderer/renderer.cc:116-142) for n rays.
  * origins, dirs: n x 3 floats.  out_t[i] = hit distance or +inf; out_tri[i] = index of the winning
  * triangle in Build order, or -1.  Ties in t go to the triangle that comes first in the reference's

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(HERE, "lib", "libraytracer_amd.so")
 
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+RT_SEARCH_NOALLOC_MAX_RAYS, RT_SEARCH_NOALLOC_SCRATCH_BYTES = 4096, 16 << 20
 RT_ADS_NONE, RT_ADS_OCTREE, RT_ADS_OCTREE_PARAMETRIC, RT_ADS_OCTREE_GPU = 0, 1, 2, 3
 RENDER_TYPES = {"distance": 0, "diffusion": 1, "phong": 2, "blinn_phong": 3}
 SHADING_TYPES = {"flat": 0, "smooth": 1}
@@ -67,7 +68,7 @@ class RenderStats(C.Structure):
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
     "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_stats",
-    "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_trace_closest", "rt_ads_trace_any",
+    "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_search_noalloc", "rt_ads_trace_closest", "rt_ads_trace_any",
     "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
     "rt_host_tree_export_flat", "rt_host_tree_stats",
@@ -105,6 +106,7 @@ def lib():
     L.rt_ads_reset_query_stats.argtypes = [vp]
     L.rt_ads_collect_search_stats.argtypes = [vp, C.c_int]
     L.rt_ads_search.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rt_ads_search_noalloc.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]
     L.rt_ads_trace_closest.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
     L.rt_ads_trace_any.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp]
     L.rt_scene_set_shading.argtypes = [vp, vp, vp, vp, C.c_uint32]

@@ -126,6 +126,10 @@ class GpuOctree(Ads):
             break
         return [out[int(offsets[i]):int(offsets[i + 1])].copy() for i in range(n)]
 
+    def search_noalloc_device(self, rays_ptr, n, offsets_ptr, out_ptr, cap, total_ptr, stream=None):
+        """rt_ads_search_noalloc: every buffer is device memory; asynchronous on `stream`; allocates nothing."""
+        _capi.check(_capi.lib().rt_ads_search_noalloc(self._h, rays_ptr, n, offsets_ptr, out_ptr, cap, total_ptr, stream))
+
     def trace_closest(self, origins, dirs, cull_backfaces=True):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
         n = o.shape[0]

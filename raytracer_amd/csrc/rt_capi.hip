@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -147,6 +148,35 @@ void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t strea
 
 }  // namespace
 
+// ---- fixed device scratch of rt_ads_search_noalloc ---------------------------------------------------------------------
+// Layout: RT_SEARCH_NOALLOC_MAX_RAYS 64-bit candidate counts, then the rays' breadth-first queues (two words per
+// entry, one queue of (octree nodes) entries per ray).  Every GPU the library runs on holds its own copy of the array
+// at its own address; `scratch` below is only the host-side stand-in of the symbol, never a pointer to pass on: the
+// device address is fetched once per device with hipGetSymbolAddress (scratch_for_device) and that pointer is what
+// kernels, memsets and copies get.
+constexpr size_t kNoallocCountBytes = (size_t)RT_SEARCH_NOALLOC_MAX_RAYS * sizeof(uint64_t);
+static __device__ __align__(256) unsigned char scratch[kNoallocCountBytes + RT_SEARCH_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// The device address of `scratch` on `device` (which must be the current device).
+int scratch_for_device(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_UNSUPPORTED, "device ordinal %d beyond %d", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned a null address for the search scratch");
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+}  // namespace
+
 struct rt_ads {
     int device = 0;
     uint32_t max_per_bb = 16, max_depth = 10;
@@ -178,6 +208,7 @@ struct rt_ads {
     DevBuf<float> d_accum, d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
     SearchWork search;
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of the fixed scratch array (rt_ads_search_noalloc)
     hipEvent_t ev[2 + 6 * kMaxTimed] = {};
     bool events_ready = false;
     rt_query_stats q{};
@@ -447,6 +478,15 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
         return fail(RT_ERR_INVALID, "unknown builder %u", cfg->builder);
     }
     a->builder = (int)cfg->builder;
+    // the fixed scratch of rt_ads_search_noalloc: its address on this device, looked up with the device current
+    {
+        hipError_t e = hipSetDevice(cfg->device);
+        int rc = e == hipSuccess ? scratch_for_device(cfg->device, &a->noalloc_scratch) : fail(RT_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+        if (rc != RT_OK) {
+            delete a;
+            return rc;
+        }
+    }
     *out = a;
     return RT_OK;
 }
@@ -908,6 +948,42 @@ int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offset
     a->q.search_return_count += returned;
     a->q.counted_rays += n;
     a->q.search_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return RT_OK;
+}
+
+int rt_ads_search_noalloc(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap,
+                          uint64_t* out_total, void* stream_) {
+    if (!a || (!rays && n) || !out_offsets || !out_total || (!out_tri && cap)) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (n > RT_SEARCH_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_CAPACITY, "rt_ads_search_noalloc takes at most %u rays per call (%llu given)", RT_SEARCH_NOALLOC_MAX_RAYS, (unsigned long long)n);
+    const uint64_t queue_cap = std::max<uint64_t>(a->n_tree_nodes, 1);
+    if (n * queue_cap * 2 * sizeof(uint32_t) > (uint64_t)RT_SEARCH_NOALLOC_SCRATCH_BYTES)
+        return fail(RT_ERR_CAPACITY, "rt_ads_search_noalloc: %llu rays x %llu octree nodes need %llu bytes of queue, the fixed scratch holds %u",
+                    (unsigned long long)n, (unsigned long long)queue_cap, (unsigned long long)(n * queue_cap * 8), RT_SEARCH_NOALLOC_SCRATCH_BYTES);
+    static_assert(RT_SEARCH_NOALLOC_MAX_RAYS <= kSearchScanMax, "one block scans the counts");
+    if (int rc = use_device(a)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* ptr = a->noalloc_scratch;  // this device's scratch array
+    uint64_t* d_counts = reinterpret_cast<uint64_t*>(ptr);
+    uint32_t* d_queue = reinterpret_cast<uint32_t*>(ptr + kNoallocCountBytes);
+    const DevOctree T = dev_tree(a);
+    const uint32_t m = (uint32_t)n;
+    // Every word of the scratch that is read has been written by this call before: the counts by the first kernel,
+    // a queue entry by the ray that later reads it.  Nothing of an earlier call's contents is used.
+    if (m) {
+        hipLaunchKernelGGL(k_search<false>, dim3((m + 63) / 64), dim3(64), 0, stream, T, rays, m, d_queue, (uint32_t)queue_cap, d_counts,
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint64_t)0, (uint64_t)0, (unsigned long long*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_search_offsets, dim3(1), dim3(256), 0, stream, (const uint64_t*)d_counts, m, out_offsets, out_total);
+    HIP_TRY(hipGetLastError());
+    if (m) {
+        hipLaunchKernelGGL(k_search<true>, dim3((m + 63) / 64), dim3(64), 0, stream, T, rays, m, d_queue, (uint32_t)queue_cap, (uint64_t*)nullptr,
+                           (const uint64_t*)out_offsets, out_tri, cap, (uint64_t)0, (unsigned long long*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    a->q.search_calls += n;
     return RT_OK;
 }
 

@@ -753,4 +753,34 @@ __global__ void __launch_bounds__(64) k_search(DevOctree T, const float* __restr
     }
 }
 
+// Exclusive prefix sum of n <= 256 * 16 candidate counts: offsets[0..n] and *total (one block of 256 threads).  Used by
+// the entry point that allocates nothing, where the whole Search batch stays on the device.
+constexpr uint32_t kSearchScanMax = 256 * 16;
+__global__ void __launch_bounds__(256) k_search_offsets(const uint64_t* __restrict__ counts, uint32_t n, uint64_t* __restrict__ offsets,
+                                                        uint64_t* __restrict__ total) {
+    __shared__ uint64_t s_sum[256];
+    const uint32_t t = threadIdx.x, first = t * 16u;
+    uint64_t local = 0;
+    for (uint32_t k = 0; k < 16u; ++k)
+        if (first + k < n) local += counts[first + k];
+    s_sum[t] = local;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint64_t v = t >= d ? s_sum[t - d] : 0ull;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = s_sum[t] - local;
+    for (uint32_t k = 0; k < 16u; ++k)
+        if (first + k < n) {
+            offsets[first + k] = run;
+            run += counts[first + k];
+        }
+    if (t == 255) {
+        offsets[n] = s_sum[255];
+        *total = s_sum[255];
+    }
+}
+
 }  // namespace rt
