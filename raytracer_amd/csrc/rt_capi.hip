@@ -204,7 +204,11 @@ struct rt_ads {
     uint32_t n_lights = 0;
     std::vector<Level> levels;
     DevBuf<uint32_t> d_counters;  // one CNT_WORDS block per level
-    uint32_t* h_counters = nullptr;
+    // what the device tells the host while a frame is in flight, in pinned host memory the kernels write directly
+    LevelSlot* h_slots = nullptr;      // one per recursion level
+    FrameTotals* h_totals = nullptr;
+    DevBuf<FrameTotals> d_totals;
+    uint32_t slot_seq = 0;
     DevBuf<float> d_accum, d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
     SearchWork search;
@@ -500,7 +504,9 @@ void rt_ads_destroy(rt_ads* a) {
     a->search.release();
     a->d_qstats.release();
     if (a->h_qstats) (void)hipHostFree(a->h_qstats);
-    if (a->h_counters) (void)hipHostFree(a->h_counters);
+    if (a->h_slots) (void)hipHostFree(a->h_slots);
+    if (a->h_totals) (void)hipHostFree(a->h_totals);
+    a->d_totals.release();
     if (a->events_ready)
         for (auto& e : a->ev) (void)hipEventDestroy(e);
     delete a;
@@ -781,7 +787,6 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
-    if (!a->h_counters) HIP_TRY(hipHostMalloc((void**)&a->h_counters, 64 * CNT_WORDS * sizeof(uint32_t)));
     a->built = true;
     return RT_OK;
 }
@@ -1133,7 +1138,8 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         t.nx = nn.x; t.ny = nn.y; t.nz = nn.z;
         t.mat = material_ids[i];
         t.light_eq = -1;
-        t.pad[0] = t.pad[1] = t.pad[2] = 0;
+        t.spawn = (mats[material_ids[i]].has_specular ? 1u : 0u) + (mats[material_ids[i]].has_transmittance ? 1u : 0u);
+        t.pad[0] = t.pad[1] = 0;
         for (size_t l = 0; l < light_tri.size(); ++l) {
             const uint32_t lt = light_tri[l];
             if (tri_equal(a->positions.data() + (size_t)lt * 9, normals ? normals + (size_t)lt * 9 : nullptr, p, normals ? normals + i * 9 : nullptr)) {
@@ -1224,9 +1230,40 @@ int ensure_events(rt_ads* a) {
     return RT_OK;
 }
 
-int read_counters(rt_ads* a, uint32_t level, hipStream_t stream) {
-    HIP_TRY(hipMemcpyAsync(a->h_counters, a->d_counters.p + (size_t)level * CNT_WORDS, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+constexpr int kMaxLevels = 32;  // renderer max_depth <= 30, plus the camera level
+
+// Waits until the closest-hit pass launched with sequence number `seq` has published its level's totals in `slot`.
+// The host polls pinned memory; the stream is not synchronised, so the device keeps running what was queued behind
+// that pass.  A stream that has drained (or failed) without the flag appearing is an error, not a reason to spin on.
+int wait_slot(const LevelSlot* slot, uint32_t seq, hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; ++spins) {
+        if (__atomic_load_n(&slot->flag, __ATOMIC_ACQUIRE) == seq) return RT_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) != 0) continue;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (spins == 0x1000 || waited > 0.05) {
+            const hipError_t e = hipStreamQuery(stream);  // also makes sure the queued work has been submitted
+            if (e == hipSuccess) {
+                if (__atomic_load_n(&slot->flag, __ATOMIC_ACQUIRE) == seq) return RT_OK;
+                return fail(RT_ERR_HIP, "internal: the stream drained but the level totals were never published");
+            }
+            if (e != hipErrorNotReady) return fail(RT_ERR_HIP, "stream failed while a level was in flight: %s", hipGetErrorString(e));
+        }
+        if (waited > 300.0) return fail(RT_ERR_HIP, "timed out waiting for a level's totals");
+    }
+}
+
+int ensure_frame_mailboxes(rt_ads* a) {
+    if (!a->h_slots) {
+        HIP_TRY(hipHostMalloc((void**)&a->h_slots, kMaxLevels * sizeof(LevelSlot), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(a->h_slots, 0, kMaxLevels * sizeof(LevelSlot));
+    }
+    if (!a->h_totals) {
+        HIP_TRY(hipHostMalloc((void**)&a->h_totals, sizeof(FrameTotals), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(a->h_totals, 0, sizeof(FrameTotals));
+    }
+    HIP_TRY(a->d_totals.reserve(1));
     return RT_OK;
 }
 
@@ -1265,103 +1302,126 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     hipEvent_t* ev_closest = a->ev + 2;
     hipEvent_t* ev_shade = a->ev + 2 + 2 * kMaxTimed;
     hipEvent_t* ev_shadow = a->ev + 2 + 4 * kMaxTimed;
+    if (int rc = ensure_frame_mailboxes(a)) return rc;
     HIP_TRY(hipEventRecord(ev_total[0], stream));
     const dim3 block(256);
     if (a->collect_stats) {
         if (int rc = stats_begin(a, stream)) return rc;
     }
+    // The frame runs without a host synchronisation.  Level sizes stay on the device: the closest-hit pass of level L
+    // reads its ray count from level L-1's counters and its last block publishes (hits, upper bound of the next level's
+    // rays) into pinned host memory; the host waits for that flag only after it has queued the level's any-hit pass, so
+    // the device never idles, and sizes the shading pass and the next level's buffers with it.  Launch grids of a level
+    // come from the published upper bound; surplus threads leave at once.
+    const uint32_t seq_base = a->slot_seq;
+    a->slot_seq = seq_base + (uint32_t)c->samples_per_pixel + 1u;  // the next frame starts beyond every sequence number of this one
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), block, 0, stream, a->d_counters.p, max_levels, a->h_slots, seq_base, a->d_totals.p);
+    HIP_TRY(hipGetLastError());
+    a->h_totals->secondary_rays = a->h_totals->shadow_rays = 0;
+    uint32_t level_seq[kMaxLevels];
+    for (auto& q : level_seq) q = seq_base;
+    const bool lit = (c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG) && a->n_lights > 0 && c->samples_per_triangle > 0;
+    const uint32_t words = (uint32_t)((std::max(c->samples_per_triangle, 1) + 31) / 32);
+    uint32_t level_n[kMaxLevels] = {};  // launch bound of each level of the current sample (resolve pass)
     for (int s = 0; s < c->samples_per_pixel && n0 > 0; ++s) {
         F.spp_sample = (uint32_t)s;
-        HIP_TRY(hipMemsetAsync(a->d_counters.p, 0, (size_t)max_levels * CNT_WORDS * sizeof(uint32_t), stream));
-        uint32_t n = n0, levels = 0;
-        for (uint32_t L = 0; L < max_levels && n > 0; ++L) {
+        uint32_t cap = n0, levels = 0;  // cap: upper bound of the level's ray count (exact for level 0)
+        for (uint32_t L = 0; L < max_levels && cap > 0; ++L) {
             Level& lv = a->levels[L];
-            HIP_TRY(lv.reserve(n, L > 0));
-            lv.n = n;
+            HIP_TRY(lv.reserve(cap, L > 0));
+            lv.n = cap;
+            level_n[L] = cap;
             uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
-            const int mode_c = traversal_mode(a, L == 0, false, n);
-            const uint32_t sparse_c = pool_sparse(a, mode_c, n, 1);
-            const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n, sparse_c) + block_c.x - 1) / block_c.x));
+            const uint32_t* n_dev = L > 0 ? cnt - CNT_WORDS + CNT_NEXT : nullptr;
+            const LevelSlot* slot = a->h_slots + L;
+            const uint32_t seq = ++level_seq[L];  // CNT_SEQ of the level after this launch
+            const int mode_c = traversal_mode(a, L == 0, false, cap);
+            const uint32_t sparse_c = pool_sparse(a, mode_c, cap, 1);
+            const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, cap, sparse_c) + block_c.x - 1) / block_c.x));
             const bool timed_c = n_timed_closest < kMaxTimed;
             if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
-            launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
+            launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
                        lv.work.p, cnt, sparse_c);
             HIP_TRY(hipGetLastError());
-            if (timed_c) {
-                HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream));
-                ++n_timed_closest;
-            }
+            if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream)); }
             st.launches_closest++;
             if (a->collect_stats) {
-                const dim3 sgrid((n + 255) / 256);
-                if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, a->d_qstats.p);
-                else hipLaunchKernelGGL(k_stats_closest<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, a->d_qstats.p);
+                const dim3 sgrid((cap + 255) / 256);
+                if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, n_dev, a->d_qstats.p);
+                else hipLaunchKernelGGL(k_stats_closest<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, n_dev, a->d_qstats.p);
                 HIP_TRY(hipGetLastError());
             }
-            if (L == 0) st.primary_rays += 0;  // counted below from the valid pixel count
-            else st.secondary_rays += n;
-            if (timed_c) st.timed_closest_rays += L == 0 ? valid_pixels : n;
-            levels = L + 1;
-            // Camera rays mostly hit something, so for level 0 the hit count stays on the device: the any-hit and
-            // shading passes are launched for the level's ray count (an upper bound; surplus blocks leave at once)
-            // and the level costs one host synchronisation (for the size of the next level) instead of two.
-            // Deeper levels often hit nothing at all; there the count is read first -- unless the level is so small
-            // that launching for all of its rays costs less than the synchronisation.
-            uint32_t n_work = n;
-            if (L > 0 && ((uint64_t)n * (uint64_t)std::max(c->samples_per_triangle, 1)) > (1ull << 24)) {
-                if (int rc = read_counters(a, L, stream)) return rc;
-                n_work = a->h_counters[CNT_WORK];
-                if (n_work == 0) break;
-            }
-            RayRec* next_rays = nullptr;
-            uint32_t next_cap = 0;
-            if (L + 1 < max_levels && a->branching_any) {
-                const uint64_t want = (uint64_t)n_work * (a->branching ? 2ull : 1ull);
-                if (want > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "recursion level too large");
-                HIP_TRY(a->levels[L + 1].reserve((uint32_t)want, true));
-                next_rays = a->levels[L + 1].rays.p;
-                next_cap = (uint32_t)want;
-            }
-            const dim3 grid_s((n_work + 255) / 256);
-            const uint32_t words = (uint32_t)((std::max(c->samples_per_triangle, 1) + 31) / 32);
-            const bool lit = c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG;
+            // The any-hit pass.  Its launch is sized by the level's hits when the host knows them, else by the level's
+            // bound (surplus threads leave at once, at about 2.3 us per million of them).  Level 0 (nearly every camera
+            // ray hits) and small levels are launched at once with the bound, so that the device never waits for the
+            // host; for a large deeper level the host first waits for the hit count -- a bubble of a few microseconds
+            // instead of an over-sized launch.
             bool timed_a = false;
-            if (lit && a->n_lights > 0 && c->samples_per_triangle > 0) {
-                HIP_TRY(lv.vis.reserve((size_t)n_work * a->n_lights * words));
+            uint32_t pshift = 0, gshift = 0;
+            while ((1u << pshift) < (uint32_t)std::max(c->samples_per_triangle, 1) && pshift < 30) ++pshift;
+            auto launch_any_hit = [&](uint32_t n_hits) -> int {
+                HIP_TRY(lv.vis.reserve((size_t)n_hits * a->n_lights * words));
                 timed_a = n_timed_shadow < kMaxTimed;
                 if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
                 // lanes per hit in the any-hit pass: the (light, sample) pairs of a hit, samples padded to a power of
-                // two per light, side by side in at most 64 lanes
-                uint32_t pshift = 0, gshift = 0;
-                while ((1u << pshift) < (uint32_t)c->samples_per_triangle && pshift < 30) ++pshift;
-                // Per-lane traversal gains from rays of one origin side by side (all lights of a hit in one wave);
-                // the wave-together forms measured faster with one light per pass (a narrower bundle of rays).
-                const int mode_a = traversal_mode(a, false, true, (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle);
+                // two per light, side by side in at most 64 lanes.  Per-lane traversal gains from rays of one origin
+                // side by side (all lights of a hit in one wave); the wave-together forms measured faster with one
+                // light per pass (a narrower bundle of rays).
+                const int mode_a = traversal_mode(a, false, true, (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle);
+                gshift = 0;
                 while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 const dim3 block_a(mode_a == MODE_WAVE ? 256 : 64);
-                const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_work << gshift, 1u << gshift);
-                const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_work << gshift, sparse_a) + block_a.x - 1) / block_a.x));
-                launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p,
+                const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
+                const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
+                launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
                            lv.work.p, lv.vis.p, words, pshift, gshift, cnt, sparse_a);
                 HIP_TRY(hipGetLastError());
-                if (timed_a) {
-                    HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream));
-                    ++n_timed_shadow;
-                }
+                if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream)); }
                 st.launches_shadow++;
                 if (a->collect_stats) {
-                    const uint64_t threads = (uint64_t)n_work * a->n_lights * (uint64_t)c->samples_per_triangle;
+                    const uint64_t threads = (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle;
                     if (threads > 0x7fffffffull * 256ull) return fail(RT_ERR_UNSUPPORTED, "level too large for the instrumented pass");
                     const dim3 sgrid((uint32_t)((threads + 255) / 256));
-                    if (F.cull) hipLaunchKernelGGL(k_stats_shadow<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
-                    else hipLaunchKernelGGL(k_stats_shadow<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
+                    if (F.cull) hipLaunchKernelGGL(k_stats_shadow<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
+                    else hipLaunchKernelGGL(k_stats_shadow<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.work.p, cnt, a->d_qstats.p);
                     HIP_TRY(hipGetLastError());
                 }
+                return RT_OK;
+            };
+            const bool any_hit_first = lit && (L == 0 || ((uint64_t)cap << std::min(pshift, 6u)) * a->n_lights < (3ull << 20));
+            if (any_hit_first) {
+                if (int rc = launch_any_hit(cap)) return rc;
             }
+            // the level's totals, published by the closest-hit pass
+            if (int rc = wait_slot(slot, seq, stream)) return rc;
+            const uint32_t n_level = slot->n, n_work = slot->n_work, spawn = slot->spawn;
+            const uint64_t level_shadow = (uint64_t)slot->shadow_lo | ((uint64_t)slot->shadow_hi << 32);
+            if (lit && !any_hit_first && n_work > 0) {
+                if (int rc = launch_any_hit(n_work)) return rc;
+            }
+            if (n_level > cap) return fail(RT_ERR_HIP, "internal: recursion queue overflow (%u > %u)", n_level, cap);
+            if (timed_c) {
+                st.timed_closest_rays += L == 0 ? valid_pixels : n_level;
+                ++n_timed_closest;
+            }
+            if (timed_a) {
+                st.timed_shadow_rays += level_shadow;
+                ++n_timed_shadow;
+            }
+            if (n_level > 0) levels = L + 1;
+            if (n_work == 0) break;  // nothing to shade, nothing spawned
+            RayRec* next_rays = nullptr;
+            uint32_t next_cap = 0;
+            if (L + 1 < max_levels && spawn > 0) {
+                HIP_TRY(a->levels[L + 1].reserve(spawn, true));
+                next_rays = a->levels[L + 1].rays.p;
+                next_cap = spawn;
+            }
+            const dim3 grid_s((n_work + 255) / 256);
             const bool timed_s = n_timed_shade < kMaxTimed;
             if (timed_s) { HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade], stream)); }
-            hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, n, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words,
+            hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words,
                                lv.out.p, next_rays, next_cap, cnt);
             HIP_TRY(hipGetLastError());
             if (timed_s) {
@@ -1369,20 +1429,18 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 ++n_timed_shade;
             }
             st.launches_shade++;
-            if (int rc = read_counters(a, L, stream)) return rc;
-            const uint64_t level_shadow = (uint64_t)a->h_counters[CNT_SHADOW_LO] | ((uint64_t)a->h_counters[CNT_SHADOW_HI] << 32);
-            st.shadow_rays += level_shadow;
-            if (timed_a) st.timed_shadow_rays += level_shadow;
-            n = a->h_counters[CNT_NEXT];
-            if (n > next_cap) return fail(RT_ERR_HIP, "internal: recursion queue overflow (%u > %u)", n, next_cap);
+            cap = next_cap;
         }
         st.levels = std::max(st.levels, levels);
         for (uint32_t L = levels; L-- > 1;) {
             Level& lv = a->levels[L];
-            hipLaunchKernelGGL(k_resolve, dim3((lv.n + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, lv.n, a->levels[L - 1].out.p);
+            const uint32_t* n_dev = a->d_counters.p + (size_t)(L - 1) * CNT_WORDS + CNT_NEXT;
+            hipLaunchKernelGGL(k_resolve, dim3((level_n[L] + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, n_dev, a->levels[L - 1].out.p);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, a->levels[0].out.p, n0, a->d_accum.p, d_out);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_roll_counters, dim3(1), block, 0, stream, a->d_counters.p, max_levels, a->d_totals.p, a->h_totals);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_total[1], stream));
@@ -1423,6 +1481,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         HIP_TRY(hipEventElapsedTime(&ms, ev_shadow[2 * k], ev_shadow[2 * k + 1]));
         st.ms_shadow += ms;
     }
+    st.secondary_rays = a->h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
+    st.shadow_rays = a->h_totals->shadow_rays;
     st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
     a->q.search_calls += st.rays;
     a->q.closest_rays += st.primary_rays + st.secondary_rays;
@@ -1447,7 +1507,8 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     Level& lv = a->levels[0];
     HIP_TRY(lv.reserve(n0, false));
     HIP_TRY(a->d_counters.reserve(CNT_WORDS));
-    HIP_TRY(hipMemsetAsync(a->d_counters.p, 0, CNT_WORDS * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(256), 0, stream, a->d_counters.p, 1u, (LevelSlot*)nullptr, 0u, (FrameTotals*)nullptr);
+    HIP_TRY(hipGetLastError());
     const size_t npix = (size_t)c->width * c->height;
     float* d_t = out_t;
     int32_t* d_tri = out_tri;
@@ -1468,8 +1529,8 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     if (a->collect_stats) {
         const SceneDev S = scene_dev(a);
         if (int rc = stats_begin(a, stream)) return rc;
-        if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, a->d_qstats.p);
-        else hipLaunchKernelGGL(k_stats_closest<false>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, a->d_qstats.p);
+        if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, (const uint32_t*)nullptr, a->d_qstats.p);
+        else hipLaunchKernelGGL(k_stats_closest<false>, grid, block, 0, stream, S, F, 0u, (const RayRec*)nullptr, n0, (const uint32_t*)nullptr, a->d_qstats.p);
         HIP_TRY(hipGetLastError());
         if (int rc = stats_end(a, stream)) return rc;
     }

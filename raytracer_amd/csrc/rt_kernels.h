@@ -12,6 +12,26 @@
 //   k_search_count / k_search_fill: Ads::Search restated (breadth-first candidate lists)
 #pragma once
 
+// Minimum waves per SIMD the register allocator must leave room for in the wave-together forms of the two level kernels
+// (their scalar register count sits at the edge of 8 waves; values live across the traversal are then kept in spare
+// vector-register lanes).  0 = no constraint.
+#ifndef RT_CLOSEST_WAVES
+#define RT_CLOSEST_WAVES 8
+#endif
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 0
+#endif
+#if RT_CLOSEST_WAVES
+#define RT_CLOSEST_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu((MODE) == 0 ? RT_CLOSEST_WAVES : 4, 8)))
+#else
+#define RT_CLOSEST_OCCUPANCY(MODE)
+#endif
+#if RT_SHADOW_WAVES
+#define RT_SHADOW_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu((MODE) == 0 ? RT_SHADOW_WAVES : 4, 8)))
+#else
+#define RT_SHADOW_OCCUPANCY(MODE)
+#endif
+
 #ifndef RT_XCD_CHUNK
 #define RT_XCD_CHUNK 16
 #endif
@@ -60,7 +80,8 @@ struct alignas(16) TriShade {  // per triangle in Build order
     float nx, ny, nz;          // face normal (src/triangle.h:28-32)
     int32_t mat;               // Triangle::material_id
     int32_t light_eq;          // first light l with lights[l] == triangle (src/triangle.h:15-19), else -1
-    int32_t pad[3];
+    uint32_t spawn;            // secondary rays a hit can spawn at most: non-zero specular + non-zero transmittance (renderer.cc:179,185)
+    int32_t pad[2];
 };
 static_assert(sizeof(TriShade) == 32, "");
 
@@ -118,7 +139,32 @@ struct FrameParams {
 };
 
 // Per-level counters.  Each sits in its own 128-byte line: atomics on one line are served one after the other.
-enum { CNT_WORK = 0, CNT_NEXT = 32, CNT_SHADOW_LO = 64, CNT_SHADOW_HI = 65, CNT_WORDS = 96 };
+// CNT_WORK: hits of the level (length of its work list); CNT_NEXT: rays appended to the next level; CNT_SHADOW: shadow
+// rays the hits cost (64 bits); CNT_SPAWN: upper bound of CNT_NEXT known after the closest-hit pass (hits whose material
+// reflects or refracts); CNT_TICKET: blocks of the closest-hit pass that have finished.  These are zeroed for every pixel
+// sample.  CNT_SEQ (launches of the level's closest-hit pass so far) and CNT_SLOT (address of the level's LevelSlot in
+// pinned host memory, 64 bits, 0 = nobody listens) are set up by k_frame_begin and live for the whole frame; keeping them
+// here rather than in kernel arguments keeps the traversal kernels' scalar register count where it was.
+enum { CNT_WORK = 0, CNT_NEXT = 32, CNT_SHADOW_LO = 64, CNT_SHADOW_HI = 65, CNT_SPAWN = 96, CNT_TICKET = 128, CNT_SEQ = 129,
+       CNT_SLOT_LO = 130, CNT_SLOT_HI = 131, CNT_WORDS = 160 };
+
+// What the host needs to know about a level to size the launches that follow, written by the last block of the
+// level's closest-hit pass straight into pinned host memory (flag last, system-scope release): the host polls the
+// flag instead of synchronising the stream, while the device already runs the level's any-hit pass.
+struct LevelSlot {
+    uint32_t n;          // rays of the level
+    uint32_t n_work;     // hits
+    uint32_t spawn;      // upper bound of the next level's rays
+    uint32_t shadow_lo, shadow_hi;
+    uint32_t pad[2];
+    uint32_t flag;       // CNT_SEQ of the launch that filled the slot
+};
+static_assert(sizeof(LevelSlot) == 32, "");
+
+// Frame totals kept on the device between the samples of a frame (k_roll_counters) and mirrored into pinned host memory.
+struct FrameTotals {
+    unsigned long long secondary_rays, shadow_rays;
+};
 
 // ---- helpers ---------------------------------------------------------------------------------------------------
 
@@ -177,30 +223,57 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // The same for a whole block (up to 1024 threads) with ONE atomic per block: a single counter word sustains only some
 // tens of atomics per microsecond, and a 1080p level has 32k waves.  Every thread of the block must call it (once per
-// kernel).  `weight` is summed over the block into the 64-bit counter at `sum64` (also one atomic per block).
+// kernel).  `weight` is summed over the block into the 64-bit counter CNT_SHADOW and `spawn` into CNT_SPAWN (one atomic
+// each per block).  The block that finishes last publishes the level's totals in the level's LevelSlot, if it has one.
 constexpr int kMaxBlockWaves = 16;
-__device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, uint32_t weight, uint32_t* sum64) {
+__device__ __forceinline__ uint32_t block_append(uint32_t* counters, bool want, uint32_t weight, uint32_t spawn, uint32_t n_level) {
     __shared__ uint32_t s_count[kMaxBlockWaves];
     __shared__ uint32_t s_weight[kMaxBlockWaves];
+    __shared__ uint32_t s_spawn[kMaxBlockWaves];
     __shared__ uint32_t s_base;
     const uint64_t m = ballot64(want);
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    uint32_t w = weight;
+    uint32_t w = weight, sp = spawn;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+        w += __shfl_xor(w, d, 64);
+        sp += __shfl_xor(sp, d, 64);
+    }
     if (lane == 0) {
         s_count[wave] = (uint32_t)__builtin_popcountll(m);
         s_weight[wave] = w;
+        s_spawn[wave] = sp;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t total = 0, wsum = 0;
+        uint32_t total = 0, wsum = 0, ssum = 0;
         for (uint32_t k = 0; k < n_waves; ++k) {
             total += s_count[k];
             wsum += s_weight[k];
+            ssum += s_spawn[k];
         }
-        s_base = total ? atomicAdd(counter, total) : 0u;
-        if (wsum) atomicAdd((unsigned long long*)sum64, (unsigned long long)wsum);
+        // The sums go in with returning atomics whose results are consumed before the ticket is taken: a returned atomic
+        // has been performed at the level where all XCDs see it, so no fence is needed between sums and ticket (an
+        // agent-scope fence writes back the whole L2 of the XCD -- per block, that costs more than the traversal).
+        const uint32_t r0 = atomicAdd(&counters[CNT_WORK], total);
+        s_base = r0;
+        const unsigned long long r1 = atomicAdd((unsigned long long*)&counters[CNT_SHADOW_LO], (unsigned long long)wsum);
+        const uint32_t r2 = atomicAdd(&counters[CNT_SPAWN], ssum);
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(r2) : "memory");
+        if (atomicAdd(&counters[CNT_TICKET], 1u) == gridDim.x - 1u) {  // every other block has added its sums
+            LevelSlot* slot = reinterpret_cast<LevelSlot*>((uintptr_t)counters[CNT_SLOT_LO] | ((uintptr_t)counters[CNT_SLOT_HI] << 32));
+            const uint32_t seq = ++counters[CNT_SEQ];
+            if (slot) {
+                const unsigned long long sh = atomicAdd((unsigned long long*)&counters[CNT_SHADOW_LO], 0ull);
+                slot->n = n_level;
+                slot->n_work = atomicAdd(&counters[CNT_WORK], 0u);
+                slot->spawn = atomicAdd(&counters[CNT_SPAWN], 0u);
+                slot->shadow_lo = (uint32_t)sh;
+                slot->shadow_hi = (uint32_t)(sh >> 32);
+                __threadfence_system();
+                __hip_atomic_store(&slot->flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     __syncthreads();
     uint32_t at = s_base;
@@ -304,9 +377,12 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 // BIG: launched with 1024-thread blocks (a quarter of the compaction atomics; only for the wave-together form on small
 // trees, see closest_block()); otherwise 256-thread blocks.
 template <bool CULL, int MODE, bool BIG>
-__global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(BIG ? 1024 : 256) RT_CLOSEST_OCCUPANCY(MODE) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
                                                  uint32_t* __restrict__ work, uint32_t* __restrict__ counters, uint32_t sparse) {
+    // n: the rays of level 0; for deeper levels an upper bound, the number itself being the previous level's CNT_NEXT
+    // (`counters` is the level's own block; the blocks of the levels are consecutive).  Threads beyond it carry no ray.
+    if (level > 0) n = counters[CNT_NEXT - CNT_WORDS];
     bool lane_ok;
     const uint32_t i = (uint32_t)ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
     bool valid;
@@ -330,14 +406,18 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) k_closest(SceneDev S, FrameP
     }
     // The shadow / area-light rays this hit will cost (renderer.cc:206-219): samples_per_triangle for every light
     // before the one the hit triangle itself is (the light loop returns there), all lights otherwise.
-    uint32_t shadow_rays = 0;
-    if (hit && F.render_type >= 2 && F.spt > 0) {
-        const int32_t light_eq = S.tri_shade[h.tri].light_eq;
-        const uint32_t lights = (light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights;
-        shadow_rays = lights * (uint32_t)F.spt;
+    // ... and the secondary rays it can spawn at most (renderer.cc:177-192: one per non-zero specular / transmittance)
+    uint32_t shadow_rays = 0, spawn = 0;
+    if (hit) {
+        const TriShade ts = S.tri_shade[h.tri];
+        if (F.render_type >= 2 && F.spt > 0) {
+            const uint32_t lights = (ts.light_eq >= 0 && (uint32_t)ts.light_eq < S.n_lights) ? (uint32_t)ts.light_eq : S.n_lights;
+            shadow_rays = lights * (uint32_t)F.spt;
+        }
+        spawn = ts.spawn;  // (the host ignores the bound at the last level)
     }
-    const uint32_t slot = block_append(&counters[CNT_WORK], hit, shadow_rays, &counters[CNT_SHADOW_LO]);
-    if (hit) work[slot] = i;
+    const uint32_t at = block_append(counters, hit, shadow_rays, spawn, n);
+    if (hit) work[at] = i;
 }
 
 // src/triangle.h:54-77
@@ -374,7 +454,7 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // WAVES: waves per block.  The kernel has no block-level step, so the per-lane and pool forms run one-wave blocks:
 // a wave that finishes frees its slot at once instead of waiting for the slowest of four.
 template <bool CULL, int MODE, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
                                                 uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters, uint32_t sparse) {
@@ -437,7 +517,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_shadow(SceneDev S, FrameParams F
 // The instrumented passes of a level (rt_stats.h): the same rays k_closest / k_shadow trace, one ray per thread.
 template <bool CULL>
 __global__ void __launch_bounds__(256) k_stats_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
-                                                       unsigned long long* __restrict__ totals) {
+                                                       const uint32_t* __restrict__ n_dev, unsigned long long* __restrict__ totals) {
+    if (n_dev) n = *n_dev;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid;
     f3 o, d;
@@ -640,10 +721,10 @@ __device__ __forceinline__ f3 node_value(const NodeOut& r) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_resolve(const NodeOut* __restrict__ cur, const RayRec* __restrict__ rays, uint32_t n,
+__global__ void __launch_bounds__(256) k_resolve(const NodeOut* __restrict__ cur, const RayRec* __restrict__ rays, const uint32_t* __restrict__ n_dev,
                                                  NodeOut* __restrict__ parent_level) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_dev) return;
     const f3 v = node_value(cur[i]);
     const RayRec r = rays[i];
     float* dst = (r.node_id & 1u) ? parent_level[r.parent].IT : parent_level[r.parent].IR;
@@ -666,6 +747,50 @@ __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const Nod
         v = clamp_color(div_guard(v, (float)F.spp));
         out_rgb[pix * 3] = v.x; out_rgb[pix * 3 + 1] = v.y; out_rgb[pix * 3 + 2] = v.z;
     }
+}
+
+// End of one pixel sample: adds the sample's per-level counts to the frame totals (mirrored into pinned host memory for
+// the host to read after the frame) and zeroes the per-level counters for the next sample.  One block.
+__global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ counters, uint32_t levels, FrameTotals* __restrict__ totals,
+                                                       FrameTotals* __restrict__ host_totals) {
+    __shared__ unsigned long long s_next, s_shadow;
+    if (threadIdx.x == 0) s_next = s_shadow = 0ull;
+    __syncthreads();
+    for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
+        const uint32_t* c = counters + (size_t)L * CNT_WORDS;
+        atomicAdd(&s_next, (unsigned long long)c[CNT_NEXT]);
+        atomicAdd(&s_shadow, (unsigned long long)c[CNT_SHADOW_LO] | ((unsigned long long)c[CNT_SHADOW_HI] << 32));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FrameTotals t = *totals;
+        t.secondary_rays += s_next;
+        t.shadow_rays += s_shadow;
+        *totals = t;
+        *host_totals = t;
+        __threadfence_system();
+    }
+    __syncthreads();
+    for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
+        uint32_t* c = counters + (size_t)L * CNT_WORDS;
+        c[CNT_WORK] = c[CNT_NEXT] = c[CNT_SHADOW_LO] = c[CNT_SHADOW_HI] = c[CNT_SPAWN] = c[CNT_TICKET] = 0u;
+    }
+}
+
+// Start of a frame: clears the counters of every level and the frame totals, and tells each level where the host
+// listens (slots + L, pinned host memory; nullptr = nowhere) and from which sequence number its launches count.
+__global__ void __launch_bounds__(256) k_frame_begin(uint32_t* __restrict__ counters, uint32_t levels, LevelSlot* slots, uint32_t seq_base,
+                                                     FrameTotals* __restrict__ totals) {
+    for (uint32_t k = threadIdx.x; k < levels * CNT_WORDS; k += blockDim.x) counters[k] = 0u;
+    __syncthreads();
+    for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
+        uint32_t* c = counters + (size_t)L * CNT_WORDS;
+        const uintptr_t p = slots ? (uintptr_t)(slots + L) : (uintptr_t)0;
+        c[CNT_SEQ] = seq_base;
+        c[CNT_SLOT_LO] = (uint32_t)p;
+        c[CNT_SLOT_HI] = (uint32_t)((uint64_t)p >> 32);
+    }
+    if (threadIdx.x == 0 && totals) totals->secondary_rays = totals->shadow_rays = 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_primary_hits(FrameParams F, const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
