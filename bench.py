@@ -5,21 +5,29 @@
 
 One step = one frame of the workload rendered through the C ABI (rt_render): primary rays, closest
 hits, area-light shadow rays (any-hit), reflection / refraction levels, with the scene resident in
-HBM.  For N > 1 (launched with torch.distributed.run, one rank per GPU) the image is cut into bands
-of 8 pixel rows dealt round-robin to the ranks, the scene is replicated, and the bands are gathered
-to rank 0 over RCCL inside the timed region (the gather of a frame overlaps the rendering of the next
-one; all of them are complete before the clock stops); the total work is fixed ("strong" scaling).
+HBM.  For N > 1 there is one rank per GPU (started by torch.distributed.run, or by this script itself
+when it is called as plain `python bench.py --gpus N`): the image is cut into bands of 8 pixel rows
+dealt round-robin to the ranks, the scene is replicated, and the bands are gathered to rank 0 over
+RCCL inside the timed region (the gather of a frame overlaps the rendering of the next one; all of
+them are complete before the clock stops); the total work is fixed ("strong" scaling).
 
 Prints ONE JSON line on rank 0.  metric = Mrays/s, one ray = one Search-equivalent query of the
-reference (primary, secondary or shadow).  `roofline` prices the dominant kernel (k_shadow: the
-any-hit pass over all area-light shadow rays) against the FP32 vector peak using the REFERENCE algorithm's work per ray
-(3 + 18*B + 52*T flops; B slab tests and T ray/triangle tests counted by the CPU restatement), and
-`cpu_baseline` is that restatement timed on one host core on a bounded sample of the same frame.
+reference (primary, secondary or shadow).
+
+`roofline` prices the dominant kernel (k_shadow: the any-hit pass over all area-light shadow rays)
+against the FP32 vector peak in two ways: `achieved` / `frac` use the REFERENCE algorithm's work per ray
+(3 + 18*B + 52*T flops with B slab tests and T ray/triangle tests per ray in the reference's
+definitions, counted on the device by the instrumented pass and cross-checked by the CPU restatement on
+a sample) -- a reference-equivalent rate; `executed_lane_ops_per_launch` / `valu_issue_frac` say what
+the kernel really issues (VALU instruction counters of a rocprofv3 pass, committed under profiles/).
+`cpu_baseline` is the CPU restatement on one host core, `cpu_baseline_all_cores` the same on all
+cores of this box (threads over image rows), `cpu_baseline_reference` the unmodified reference binary.
+`other_workloads` carries a few frames of the other single-GPU benchmark configurations.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -52,10 +60,154 @@ WORKLOADS = {
         shading="flat", cull=True, max_depth=10, cpu_rows=(96, 160)),
 }
 DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
+# frames of the other configurations that the default single-GPU run appends to its line
+OTHER_WORKLOADS = {"cornell_sphere_blinn_smooth_spp4_1080p": 4, "synthetic_ico8_phong_4k": 5, "cornell_original_blinn_spp64_spt32_4k": 2}
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 FP32_NO_FMA_PEAK_TOPS = 78.6      # the same lanes issuing one non-fused op per clock (bit-parity forbids FMA)
 HBM_PEAK_GBPS = 8000.0
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run as a child
+    process, before this process has touched torch or HIP) and pass rank 0's JSON line through."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def load_scene(wl, Scene):
+    if wl["scene"].startswith("synthetic:"):
+        from raytracer_amd.synthetic import cornell_with_icosphere
+        box = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", "cornell_original.npz"))
+        return cornell_with_icosphere(box, int(wl["scene"].split(":")[1]))
+    return Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
+
+
+def render_kwargs(wl):
+    aspect = 1 if wl.get("aspect") == "true" else 0
+    return dict(fov=0.6, width=wl["width"], height=wl["height"], spp=wl["spp"], spt=wl["spt"], render_type=wl["render_type"],
+                shading=wl["shading"], cull=wl["cull"], max_depth=wl["max_depth"], seed=42, aspect_mode=aspect, **wl["cam"])
+
+
+def reference_work(ads, rt, wl, max_rays=6e7):
+    """B (slab tests) and T (ray/triangle tests) per ray in the REFERENCE's definitions, for any-hit and closest-hit
+    rays separately, counted on the device by the instrumented pass (rt_ads_collect_search_stats) on this workload's
+    frame -- at a reduced image size if the full frame has more than max_rays rays (per-ray averages do not depend on
+    the size; samples per pixel are reduced to 1 for the same reason)."""
+    kw = render_kwargs(wl)
+    kw["spp"] = 1
+    est = wl["width"] * wl["height"] * (1.0 + 2.2 * wl["spt"])
+    k = 1
+    while est / (k * k) > max_rays:
+        k += 1
+    kw["width"], kw["height"] = max(64, wl["width"] // k), max(64, wl["height"] // k)
+    if wl.get("aspect") != "true" and wl["height"] < wl["width"]:
+        kw["height"] = min(kw["height"], 64)  # compat aspect with width > height: every row is the same scanline
+    ads.reset_query_stats()
+    ads.collect_search_stats(True)
+    ads.render(rt.make_render_config(**kw))
+    ads.collect_search_stats(False)
+    q = ads.query_stats()
+    n_any = max(q["counted_rays_any"], 1)
+    n_cl = max(q["counted_rays"] - q["counted_rays_any"], 1)
+    b_any, t_any = q["slab_tests_any"] / n_any, q["ray_triangle_tests_any"] / n_any
+    b_cl = (q["slab_tests"] - q["slab_tests_any"]) / n_cl
+    t_cl = (q["ray_triangle_tests"] - q["ray_triangle_tests_any"]) / n_cl
+    return {"any_hit": {"B": b_any, "T": t_any, "flops": 3 + 18 * b_any + 52 * t_any},
+            "closest_hit": {"B": b_cl, "T": t_cl, "flops": 3 + 18 * b_cl + 52 * t_cl},
+            "counted_on": f"device, instrumented pass, {kw['width']}x{kw['height']} frame of the same workload, {q['counted_rays']} rays"}
+
+
+def kernel_summary(acc, steps, work):
+    """Per-kernel-class rates from the HIP-event times that rt_render reports (first 64 launches of each class per frame)."""
+    shadow_rate = acc["shadow_rays"] / max(acc["shadow_ms"] * 1e-3, 1e-12)
+    closest_rate = acc["closest_rays"] / max(acc["closest_ms"] * 1e-3, 1e-12)
+    out = {"k_shadow": {"launches": acc["shadow_launches"], "avg_launch_ms": acc["shadow_ms"] / max(acc["shadow_launches"], 1),
+                        "ms_per_frame": acc["shadow_ms"] / steps, "Mrays_per_s": shadow_rate / 1e6},
+           "k_closest": {"launches": acc["closest_launches"], "avg_launch_ms": acc["closest_ms"] / max(acc["closest_launches"], 1),
+                         "ms_per_frame": acc["closest_ms"] / steps, "Mrays_per_s": closest_rate / 1e6},
+           "k_shade": {"launches": acc["shade_launches"], "avg_launch_ms": acc["shade_ms"] / max(acc["shade_launches"], 1),
+                       "ms_per_frame": acc["shade_ms"] / steps}}
+    if work is not None:
+        for name, rate, key in (("k_shadow", shadow_rate, "any_hit"), ("k_closest", closest_rate, "closest_hit")):
+            tf = rate * work[key]["flops"] / 1e12
+            out[name]["reference_equivalent_TFLOPs"] = tf
+            out[name]["frac_of_fp32_vector_peak"] = tf / FP32_VECTOR_PEAK_TFLOPS
+            out[name]["frac_of_no_fma_issue_peak"] = tf / FP32_NO_FMA_PEAK_TOPS
+    return out
+
+
+def new_acc():
+    return dict(rays=0, shade_ms=0.0, closest_ms=0.0, shadow_ms=0.0, shade_launches=0, closest_launches=0, shadow_launches=0,
+                shadow_rays=0, closest_rays=0)
+
+
+def add_stats(acc, st):
+    acc["rays"] += st.rays
+    acc["shade_ms"] += st.ms_shade
+    acc["closest_ms"] += st.ms_closest
+    acc["shadow_ms"] += st.ms_shadow
+    # per-kernel times come from HIP events around the first 64 launches of each class in a call; the ray counts
+    # used for kernel rates are those of exactly these launches
+    acc["shade_launches"] += min(st.launches_shade, 64)
+    acc["shadow_launches"] += min(st.launches_shadow, 64)
+    acc["closest_launches"] += min(st.launches_closest, 64)
+    acc["shadow_rays"] += st.timed_shadow_rays
+    acc["closest_rays"] += st.timed_closest_rays
+
+
+def run_other_workload(name, frames, rt, Scene, torch):
+    """A few frames of another benchmark configuration on this GPU (device-resident frame buffer, one rank)."""
+    wl = WORKLOADS[name]
+    scene = load_scene(wl, Scene)
+    ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    ads.Build(scene.pos)
+    ads.set_shading(scene.norm, scene.matid, scene.materials)
+    cfg = rt.make_render_config(**render_kwargs(wl))
+    frame = torch.zeros((wl["height"] + 8, wl["width"], 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    acc = new_acc()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        _, st = ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
+        add_stats(acc, st)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    work = reference_work(ads, rt, wl)
+    ts = ads.tree_stats()
+    ks = kernel_summary(acc, frames, work)
+    res = {"Mrays_per_s": acc["rays"] / elapsed / 1e6, "ms_per_frame": elapsed / frames * 1e3, "frames": frames,
+           "rays_per_frame": acc["rays"] // frames, "triangles": scene.n_triangles, "octree_nodes": ts["nodes"],
+           "octree_build_s": round(ts["build_seconds"], 4), "reference_work_per_ray": work, "kernels": ks,
+           "k_shadow_frac": ks["k_shadow"].get("frac_of_fp32_vector_peak"), "k_closest_frac": ks["k_closest"].get("frac_of_fp32_vector_peak")}
+    ads.close()
+    del frame
+    return res
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    n = int(os.environ.get("OMP_NUM_THREADS") or 0) or 16
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        n = min(n, os.cpu_count() or 1)
+    return max(1, n)
 
 
 def main():
@@ -65,7 +217,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed frames: no reference-work pass, no other workloads, no host-framebuffer timing (counter passes)")
+    ap.add_argument("--no-other-workloads", action="store_true")
     args = ap.parse_args()
+
+    # RT_BENCH_SELF_LAUNCH=1 takes the self-launch path with one rank too (a check of it on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("RT_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     # stdout carries exactly one JSON line.  Native libraries (RCCL prints a version banner when a communicator is
     # created) write to file descriptor 1 directly, so everything but the final line is sent to stderr.
@@ -82,8 +241,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
@@ -100,20 +257,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
-    if wl["scene"].startswith("synthetic:"):
-        from raytracer_amd.synthetic import cornell_with_icosphere
-        box = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", "cornell_original.npz"))
-        scene = cornell_with_icosphere(box, int(wl["scene"].split(":")[1]))
-    else:
-        scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
+    scene = load_scene(wl, Scene)
     ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=local_rank)
     ads.Build(scene.pos)
     ads.set_shading(scene.norm, scene.matid, scene.materials)
     tree_stats = ads.tree_stats()
     W, H = wl["width"], wl["height"]
-    aspect = 1 if wl.get("aspect") == "true" else 0
-    kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=wl["render_type"], shading=wl["shading"],
-              cull=wl["cull"], max_depth=wl["max_depth"], seed=42, aspect_mode=aspect, **wl["cam"])
+    kw = render_kwargs(wl)
+    aspect = kw["aspect_mode"]
     cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
 
     from raytracer_amd import distributed as rd
@@ -148,25 +299,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    rays = 0
-    shade_ms = closest_ms = shadow_ms = 0.0
-    shade_launches = closest_launches = shadow_launches = 0
-    shadow_rays = closest_rays = 0
+    acc = new_acc()
     for _ in range(args.steps):
-        st = step()
-        rays += st.rays
-        shade_ms += st.ms_shade
-        closest_ms += st.ms_closest
-        # per-kernel times come from HIP events around the first 64 launches of each class in a call; the ray
-        # counts used for kernel rates are those of exactly these launches
-        shade_launches += min(st.launches_shade, 64)
-        shadow_ms += st.ms_shadow
-        shadow_launches += min(st.launches_shadow, 64)
-        closest_launches += min(st.launches_closest, 64)
-        shadow_rays += st.timed_shadow_rays
-        closest_rays += st.timed_closest_rays
+        add_stats(acc, step())
     fence()
     elapsed = time.perf_counter() - t0
+    rays = acc["rays"]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -191,33 +329,57 @@ def main():
                        "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3),
                        "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)"},
         }
-        # ---- CPU baseline + reference-work counts on a bounded sample of the same frame (rank 0, N = 1 only) ----
-        flops_any = flops_closest = None
-        if world == 1 and not args.no_cpu_baseline:
+        work = None
+        if world == 1 and not args.no_extras:
+            # reference work per ray, counted on the device in the reference's definitions (whole reduced frame)
+            work = reference_work(ads, rt, wl)
+            out["reference_work_per_ray"] = work
+        # ---- CPU baselines on bounded samples of the same frame (rank 0, N = 1 only) ----
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc
             osc = orc.Scene.from_arrays(scene.pos, scene.norm, scene.matid, scene.materials)
             otree = orc.Octree(osc, 16, 10)
             r0, r1 = wl["cpu_rows"]
-            ocfg = orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(r0, r1), **kw)
+            okw = {k: v for k, v in kw.items()}
+            ocfg = orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(r0, r1), **okw)
             c0 = time.perf_counter()
             ref, _, _, ost = orc.render(osc, otree, ocfg, want_hits=False)
             cpu_s = time.perf_counter() - c0
             img = frame[:H].cpu().numpy()
             diff = float(np.abs(img[r0:r1] - ref[r0:r1]).max())
-            out["cpu_baseline"] = {"value": ost.search_calls / cpu_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            model = cpu_model()
+            out["cpu_baseline"] = {"value": ost.search_calls / cpu_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "cpu": model,
                                    "sample": f"rows {r0}..{r1 - 1} of the same frame ({ost.search_calls} rays, {cpu_s:.1f} s), "
                                              "oracle/rt_oracle.c -O2, counter RNG"}
             out["parity_on_sample"] = {"max_abs_diff": diff, "tolerance": 1.0 / 255.0, "ok": diff <= 1.0 / 255.0}
+            # the CPU restatement's own count of the reference work on the sampled rows: cross-check of the device counters
             n_any = max(ost.shadow_rays, 1)
             n_closest = max(ost.primary_rays + ost.secondary_rays, 1)
-            b_any, t_any = ost.slab_tests_any / n_any, ost.tri_tests_any / n_any
-            b_cl = (ost.slab_tests - ost.slab_tests_any) / n_closest
-            t_cl = (ost.tri_tests - ost.tri_tests_any) / n_closest
-            flops_any = 3 + 18 * b_any + 52 * t_any
-            flops_closest = 3 + 18 * b_cl + 52 * t_cl
-            out["reference_work_per_ray"] = {"any_hit": {"B": b_any, "T": t_any, "flops": flops_any},
-                                             "closest_hit": {"B": b_cl, "T": t_cl, "flops": flops_closest}}
+            out["reference_work_per_ray"]["cpu_cross_check"] = {
+                "any_hit": {"B": ost.slab_tests_any / n_any, "T": ost.tri_tests_any / n_any},
+                "closest_hit": {"B": (ost.slab_tests - ost.slab_tests_any) / n_closest, "T": (ost.tri_tests - ost.tri_tests_any) / n_closest},
+                "counted_on": f"oracle, rows {r0}..{r1 - 1}"}
+            # all host cores of this box: threads over row blocks of the same restatement (the C code releases the GIL;
+            # the counter generator makes rows independent), sized to about 16x the single-core sample
+            threads = host_threads()
+            rows_total = min(H, (r1 - r0) * max(threads, 1))
+            a0 = max(0, min(r0, H - rows_total))
+            edges = [a0 + (rows_total * i) // (threads * 4) for i in range(threads * 4 + 1)]
+            jobs = [(edges[i], edges[i + 1]) for i in range(threads * 4) if edges[i + 1] > edges[i]]
+            from concurrent.futures import ThreadPoolExecutor
+
+            def job(rows):
+                _, _, _, s_ = orc.render(osc, otree, orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=rows, **okw), want_hits=False)
+                return s_.search_calls
+
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                all_rays = sum(ex.map(job, jobs))
+            all_s = time.perf_counter() - c0
+            out["cpu_baseline_all_cores"] = {"value": all_rays / all_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu": model,
+                                             "sample": f"rows {a0}..{a0 + rows_total - 1} of the same frame in {len(jobs)} row blocks over "
+                                                       f"{threads} threads ({all_rays} rays, {all_s:.1f} s), oracle/rt_oracle.c -O2, counter RNG"}
             # The unmodified reference binary itself (built from the reference's sources where they exist; the binary
             # travels with the repository), on the same scene and settings at a reduced image size, one sample per
             # pixel: about 5 M rays.  The time is the whole process (scene load, Build, frame, PPM write).
@@ -230,10 +392,10 @@ def main():
                                     shading=wl["shading"], cull=wl["cull"], max_depth=wl["max_depth"],
                                     max_distance=wl["cam"]["max_distance"])
                 out["cpu_baseline_reference"] = {
-                    "value": rr["search_calls"] / rr["wall_s"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                    "value": rr["search_calls"] / rr["wall_s"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference", "cpu": model,
                     "sample": f"oracle/_ref/raytracer_ref (-O2, glibc rand) on the same scene and settings at {rw}x{rh}, 1 sample "
                               f"per pixel: {rr['search_calls']} Search calls in {rr['wall_s']:.1f} s (whole process)"}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the same frame with the framebuffer handed back in host memory (device -> host copy inside the call);
             # reported beside `value`, never as it
             host_img = np.empty((H, W, 3), np.float32)
@@ -245,35 +407,52 @@ def main():
             host_s = (time.perf_counter() - h0) / n_host
             out["host_framebuffer"] = {"Mrays_per_s": hst.rays / host_s / 1e6, "ms_per_frame": host_s * 1e3,
                                        "note": "rt_render with RT_MEM_HOST output: adds the PCIe copy of the frame"}
-        kernel_rate = shadow_rays / max(shadow_ms * 1e-3, 1e-12) / 1e6
-        roof = {"bound": "valu", "kernel": "k_shadow (any-hit pass: area-light shadow rays)", "achieved": None,
-                "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                "launches": shadow_launches, "avg_launch_ms": shadow_ms / max(shadow_launches, 1),
-                "rays_per_launch": shadow_rays / max(shadow_launches, 1), "kernel_Mrays_per_s": kernel_rate,
-                "other_kernels": {"k_closest": {"launches": closest_launches, "avg_launch_ms": closest_ms / max(closest_launches, 1),
-                                                "Mrays_per_s": closest_rays / max(closest_ms * 1e-3, 1e-12) / 1e6},
-                                  "k_shade": {"launches": shade_launches, "avg_launch_ms": shade_ms / max(shade_launches, 1)}}}
-        if flops_any is not None and shadow_ms > 0:
-            tflops = shadow_rays * flops_any / (shadow_ms * 1e-3) / 1e12
-            roof.update({"achieved": tflops, "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
-                         "frac_of_no_fma_issue_peak": tflops / FP32_NO_FMA_PEAK_TOPS, "algorithmic_flops_per_ray": flops_any})
-            roof["other_kernels"]["k_closest"]["achieved_TFLOPs"] = closest_rays * flops_closest / max(closest_ms * 1e-3, 1e-12) / 1e12
-        # HBM bytes per k_shadow launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
-        # same command; they cannot be collected from inside the run, so the committed summary is quoted.
+        ks = kernel_summary(acc, args.steps, work)
+        sh = ks["k_shadow"]
+        roof = {"bound": "valu", "kernel": "k_shadow (any-hit pass: area-light shadow rays)",
+                "achieved": sh.get("reference_equivalent_TFLOPs"), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": sh.get("frac_of_fp32_vector_peak"), "traffic": None,
+                "achieved_is": "reference-equivalent work: rays x (3 + 18 B + 52 T) flops of the reference algorithm per ray / kernel time; "
+                               "the kernel executes less (shared plane products, early exits, no duplicate triangles) and, bit-exact "
+                               "without FMA, can issue at most 78.6 T lane-ops/s",
+                "frac_of_no_fma_issue_peak": sh.get("frac_of_no_fma_issue_peak"),
+                "algorithmic_flops_per_ray": work["any_hit"]["flops"] if work else None,
+                "launches": sh["launches"], "avg_launch_ms": sh["avg_launch_ms"],
+                "rays_per_launch": acc["shadow_rays"] / max(acc["shadow_launches"], 1), "kernel_Mrays_per_s": sh["Mrays_per_s"],
+                "other_kernels": {"k_closest": ks["k_closest"], "k_shade": ks["k_shade"]}}
+        # Counter evidence comes from separate rocprofv3 --pmc passes of this same command (tools/pmc_profile.sh); they
+        # cannot be collected from inside the run, so the committed summary of the latest round is quoted.
         import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
         if pmc_files and world == 1:
             with open(pmc_files[-1]) as f:
                 pmc = json.load(f)
-            if pmc.get("workload") == args.workload:
-                roof["traffic"] = pmc["k_shadow_bytes_per_launch_corrected"]["mean_over_launches"]
-                roof["traffic_source"] = (f"profiles/{os.path.basename(pmc_files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
-                                          "separate runs, reads doubled per the gfx950 rule; bytes per launch)")
-                # per hit: work index + t + triangle index read (12 B), one visibility word per light and 32 samples written
-                n_lights = max(len(scene.light_triangles()), 1)
-                hits = (shadow_rays / max(shadow_launches, 1)) / (wl["spt"] * n_lights)
-                roof["algorithmic_bytes_per_launch"] = hits * (12.0 + 4.0 * n_lights * ((wl["spt"] + 31) // 32))
+            k = pmc.get("workloads", {}).get(args.workload, {}).get("kernels", {}).get("k_shadow")
+            if k:
+                src = f"profiles/{os.path.basename(pmc_files[-1])}"
+                if "bytes_per_launch" in k:
+                    roof["traffic"] = k["bytes_per_launch"]
+                    roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, reads doubled per the gfx950 rule; bytes per launch)"
+                    n_lights = max(len(scene.light_triangles()), 1)
+                    hits = (acc["shadow_rays"] / max(acc["shadow_launches"], 1)) / (wl["spt"] * n_lights)
+                    # per hit: work index + t + triangle index read (12 B), one visibility word per light and 32 samples written
+                    roof["algorithmic_bytes_per_launch"] = hits * (12.0 + 4.0 * n_lights * ((wl["spt"] + 31) // 32))
+                    roof["hbm_frac"] = roof["traffic"] / (sh["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                if "valu_lane_ops_per_launch" in k:
+                    roof["executed_lane_ops_per_launch"] = k["valu_lane_ops_per_launch"]
+                    roof["executed_valu_insts_per_launch"] = k.get("SQ_INSTS_VALU")
+                    roof["executed_salu_insts_per_launch"] = k.get("SQ_INSTS_SALU")
+                    roof["valu_issue_frac"] = k["valu_lane_ops_per_launch"] / (sh["avg_launch_ms"] * 1e-3) / 1e12 / FP32_NO_FMA_PEAK_TOPS
+                    roof["valu_busy_frac_profiled"] = k.get("valu_busy_frac")
+                    roof["lds_bank_conflict_frac"] = k.get("lds_bank_conflict_frac")
+                    roof["counters_source"] = src + " (rocprofv3 --pmc SQ_* passes, per-launch means; valu_issue_frac divides the executed wave64 " \
+                                                    "VALU lane-ops by this run's kernel time and the 78.6 T lane-ops/s issue peak)"
         out["roofline"] = roof
+        if world == 1 and not args.no_extras and not args.no_other_workloads and args.workload == DEFAULT_WORKLOAD:
+            others = {}
+            for name, n_frames in OTHER_WORKLOADS.items():
+                others[name] = run_other_workload(name, n_frames, rt, Scene, torch)
+            out["other_workloads"] = others
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

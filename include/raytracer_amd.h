@@ -120,6 +120,8 @@ typedef struct rt_query_stats {
     uint64_t slab_tests;
     uint64_t counted_rays;
     double search_seconds;           /* "Search time": device time of the traversal kernels (rt_render) or wall time of the call */
+    /* the part of slab_tests / ray_triangle_tests / counted_rays that belongs to any-hit (shadow) rays */
+    uint64_t slab_tests_any, ray_triangle_tests_any, counted_rays_any;
 } rt_query_stats;
 int rt_ads_query_stats(const rt_ads* ads, rt_query_stats* out);
 int rt_ads_reset_query_stats(rt_ads* ads);

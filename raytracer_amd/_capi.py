@@ -37,7 +37,8 @@ class QueryStats(C.Structure):
     _fields_ = [("search_calls", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64),
                 ("search_node_count", C.c_uint64), ("search_return_count", C.c_uint64), ("search_leaves_visited", C.c_uint64),
                 ("ray_triangle_tests", C.c_uint64), ("slab_tests", C.c_uint64), ("counted_rays", C.c_uint64),
-                ("search_seconds", C.c_double)]
+                ("search_seconds", C.c_double), ("slab_tests_any", C.c_uint64), ("ray_triangle_tests_any", C.c_uint64),
+                ("counted_rays_any", C.c_uint64)]
 
 
 class RenderConfig(C.Structure):

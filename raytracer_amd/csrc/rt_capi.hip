@@ -313,6 +313,9 @@ int stats_end(rt_ads* a, hipStream_t stream) {  // synchronises the stream
     a->q.slab_tests += a->h_qstats[QS_SLAB];
     a->q.ray_triangle_tests += a->h_qstats[QS_TRI];
     a->q.counted_rays += a->h_qstats[QS_RAYS];
+    a->q.slab_tests_any += a->h_qstats[QS_ANY + QS_SLAB];
+    a->q.ray_triangle_tests_any += a->h_qstats[QS_ANY + QS_TRI];
+    a->q.counted_rays_any += a->h_qstats[QS_ANY + QS_RAYS];
     return RT_OK;
 }
 

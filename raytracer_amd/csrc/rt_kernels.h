@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) k_stats_rays(DevOctree T, const float* __
     }
     RayCounters c;
     stats_ray<ANY, CULL>(T, valid, o, d, t_limit, c);
-    stats_flush(c, totals);
+    stats_flush<ANY>(c, totals);
 }
 
 // ---- renderer level kernels ------------------------------------------------------------------------------------
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256) k_stats_shadow(SceneDev S, FrameParams F,
     const f3 d_l = normalize(to_l);
     RayCounters c;
     stats_ray<true, CULL>(S.tree, on, P, d_l, dist, c);
-    stats_flush(c, totals);
+    stats_flush<true>(c, totals);
 }
 
 // Local illumination + recursion gate + secondary ray construction for every hit of one level

@@ -29,7 +29,9 @@
 
 namespace rt {
 
-enum { QS_NODES = 0, QS_LEAVES = 1, QS_RETURNED = 2, QS_SLAB = 3, QS_TRI = 4, QS_RAYS = 5, QS_WORDS = 8 };
+// Totals of the instrumented pass; any-hit rays add to the first block AND to the second one (offset QS_ANY), which
+// mirrors the reference-work split that a per-kernel roofline needs.
+enum { QS_NODES = 0, QS_LEAVES = 1, QS_RETURNED = 2, QS_SLAB = 3, QS_TRI = 4, QS_RAYS = 5, QS_ANY = 8, QS_WORDS = 16 };
 
 struct RayCounters {
     uint32_t nodes = 0, leaves = 0, returned = 0, slab = 0, tri = 0, rays = 0;
@@ -126,6 +128,7 @@ __device__ __forceinline__ void stats_ray(const DevOctree& T, bool valid, f3 o, 
 }
 
 // Adds the lanes' counters to the 64-bit totals at `out` (QS_* order): one atomic per counter and wave.
+template <bool ANY = false>
 __device__ __forceinline__ void stats_flush(const RayCounters& c, unsigned long long* __restrict__ out) {
     uint32_t v[6] = {c.nodes, c.leaves, c.returned, c.slab, c.tri, c.rays};
 #pragma unroll
@@ -133,7 +136,10 @@ __device__ __forceinline__ void stats_flush(const RayCounters& c, unsigned long 
         unsigned long long x = v[k];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
-        if (__lane_id() == 0 && x) atomicAdd(&out[k], x);
+        if (__lane_id() == 0 && x) {
+            atomicAdd(&out[k], x);
+            if (ANY) atomicAdd(&out[QS_ANY + k], x);
+        }
     }
 }
 

@@ -12,13 +12,12 @@ from raytracer_amd.scene import Scene  # noqa: E402
 import bench  # noqa: E402
 
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT_WORKLOAD]
-scene = Scene.load_npz(os.path.join(bench.ROOT, "tests", "golden", "scenes", wl["scene"] + ".npz"))
+scene = bench.load_scene(wl, Scene)
 ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
 ads.Build(scene.pos)
 ads.set_shading(scene.norm, scene.matid, scene.materials)
 W, H = wl["width"], wl["height"]
-kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=wl["render_type"], shading=wl["shading"],
-          cull=wl["cull"], max_depth=wl["max_depth"], seed=42, **wl["cam"])
+kw = bench.render_kwargs(wl)
 frame = torch.zeros((H + 64, W, 3), dtype=torch.float32, device="cuda")
 worlds = [int(x) for x in os.environ.get('BAND_WORLDS', '1,2,4,8').split(',')]
 for world in worlds:
@@ -28,9 +27,9 @@ for world in worlds:
             ads.render(cfg, out_ptr=frame.data_ptr())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 20
+        n = int(os.environ.get("BAND_FRAMES", "20"))
         for _ in range(n):
             _, st = ads.render(cfg, out_ptr=frame.data_ptr())
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        print(f"world {world} rank {rank}: {ms:.3f} ms/frame, rays {st.rays}, kernels {st.ms_closest + st.ms_shadow + st.ms_shade:.3f} ms, total(ev) {st.ms_total:.3f}")
+        print(f"{sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT_WORKLOAD} world {world} rank {rank}: {ms:.3f} ms/frame, rays {st.rays}, kernels {st.ms_closest + st.ms_shadow + st.ms_shade:.3f} ms, total(ev) {st.ms_total:.3f}")

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/pmc_pass
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $WL > "$OUT/log.txt" 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --workload $WL > "$OUT/log.txt" 2>&1
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, os, collections

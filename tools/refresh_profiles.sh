@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles_new"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 cd /tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats pass done"

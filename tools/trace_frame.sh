@@ -12,7 +12,7 @@ if [ "$1" = "--cmd" ]; then
   shift
   timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$@" > "$OUT/log.txt" 2>&1
 else
-  timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > "$OUT/log.txt" 2>&1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --workload $WL > "$OUT/log.txt" 2>&1
 fi
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
