@@ -1300,11 +1300,30 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     rt_render_stats st{};
     uint64_t valid_pixels = 0;  // of this call's bands, per sample
     for (int b = c->band_rank; b < (c->height + 7) / 8; b += c->band_world) valid_pixels += (uint64_t)std::min(8, c->height - b * 8) * (uint64_t)c->width;
-    int n_timed_closest = 0, n_timed_shade = 0, n_timed_shadow = 0;
+    // Per-class kernel times: ONE event per boundary between timed kernels -- the event that ends a kernel's interval
+    // starts the next one's (an event costs the stream about 5 us; two per boundary were 2-3 % of a 2.5 ms frame).
+    // mark(cls) closes the open interval and opens one of class cls; CLS_OTHER only closes.  At most kMaxTimed
+    // intervals per class are taken per call.
+    enum { CLS_OTHER = 0, CLS_CLOSEST = 1, CLS_SHADOW = 2, CLS_SHADE = 3 };
+    constexpr int kMaxMarks = 6 * kMaxTimed;
     hipEvent_t* ev_total = a->ev;
-    hipEvent_t* ev_closest = a->ev + 2;
-    hipEvent_t* ev_shade = a->ev + 2 + 2 * kMaxTimed;
-    hipEvent_t* ev_shadow = a->ev + 2 + 4 * kMaxTimed;
+    hipEvent_t* ev_mark = a->ev + 2;
+    int n_marks = 0, n_cls[4] = {0, 0, 0, 0};
+    uint8_t mark_cls[kMaxMarks];
+    bool last_timed = false;
+    auto mark = [&](int cls) -> int {
+        const bool want = cls != CLS_OTHER && n_cls[cls] < kMaxTimed;
+        last_timed = want;
+        if (!want && (n_marks == 0 || mark_cls[n_marks - 1] == CLS_OTHER)) return RT_OK;  // no interval is open
+        if (n_marks >= kMaxMarks) {
+            last_timed = false;
+            return RT_OK;
+        }
+        HIP_TRY(hipEventRecord(ev_mark[n_marks], stream));
+        mark_cls[n_marks++] = (uint8_t)(want ? cls : CLS_OTHER);
+        if (want) ++n_cls[cls];
+        return RT_OK;
+    };
     if (int rc = ensure_frame_mailboxes(a)) return rc;
     HIP_TRY(hipEventRecord(ev_total[0], stream));
     const dim3 block(256);
@@ -1341,14 +1360,14 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const int mode_c = traversal_mode(a, L == 0, false, cap);
             const uint32_t sparse_c = pool_sparse(a, mode_c, cap, 1);
             const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, cap, sparse_c) + block_c.x - 1) / block_c.x));
-            const bool timed_c = n_timed_closest < kMaxTimed;
-            if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest], stream)); }
+            if (int rc = mark(CLS_CLOSEST)) return rc;
+            const bool timed_c = last_timed;
             launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
                        lv.work.p, cnt, sparse_c);
             HIP_TRY(hipGetLastError());
-            if (timed_c) { HIP_TRY(hipEventRecord(ev_closest[2 * n_timed_closest + 1], stream)); }
             st.launches_closest++;
             if (a->collect_stats) {
+                if (int rc = mark(CLS_OTHER)) return rc;
                 const dim3 sgrid((cap + 255) / 256);
                 if (F.cull) hipLaunchKernelGGL(k_stats_closest<true>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, n_dev, a->d_qstats.p);
                 else hipLaunchKernelGGL(k_stats_closest<false>, sgrid, block, 0, stream, S, F, L, lv.rays.p, cap, n_dev, a->d_qstats.p);
@@ -1364,8 +1383,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             while ((1u << pshift) < (uint32_t)std::max(c->samples_per_triangle, 1) && pshift < 30) ++pshift;
             auto launch_any_hit = [&](uint32_t n_hits) -> int {
                 HIP_TRY(lv.vis.reserve((size_t)n_hits * a->n_lights * words));
-                timed_a = n_timed_shadow < kMaxTimed;
-                if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow], stream)); }
+                if (int rc = mark(CLS_SHADOW)) return rc;
+                timed_a = last_timed;
                 // lanes per hit in the any-hit pass: the (light, sample) pairs of a hit, samples padded to a power of
                 // two per light, side by side in at most 64 lanes.  Per-lane traversal gains from rays of one origin
                 // side by side (all lights of a hit in one wave); the wave-together forms measured faster with one
@@ -1380,9 +1399,9 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
                            lv.work.p, lv.vis.p, words, pshift, gshift, cnt, sparse_a);
                 HIP_TRY(hipGetLastError());
-                if (timed_a) { HIP_TRY(hipEventRecord(ev_shadow[2 * n_timed_shadow + 1], stream)); }
                 st.launches_shadow++;
                 if (a->collect_stats) {
+                    if (int rc = mark(CLS_OTHER)) return rc;
                     const uint64_t threads = (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle;
                     if (threads > 0x7fffffffull * 256ull) return fail(RT_ERR_UNSUPPORTED, "level too large for the instrumented pass");
                     const dim3 sgrid((uint32_t)((threads + 255) / 256));
@@ -1395,6 +1414,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const bool any_hit_first = lit && (L == 0 || ((uint64_t)cap << std::min(pshift, 6u)) * a->n_lights < (3ull << 20));
             if (any_hit_first) {
                 if (int rc = launch_any_hit(cap)) return rc;
+            } else {
+                if (int rc = mark(CLS_OTHER)) return rc;  // the host's wait below is not the closest-hit pass's time
             }
             // the level's totals, published by the closest-hit pass
             if (int rc = wait_slot(slot, seq, stream)) return rc;
@@ -1404,16 +1425,13 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 if (int rc = launch_any_hit(n_work)) return rc;
             }
             if (n_level > cap) return fail(RT_ERR_HIP, "internal: recursion queue overflow (%u > %u)", n_level, cap);
-            if (timed_c) {
-                st.timed_closest_rays += L == 0 ? valid_pixels : n_level;
-                ++n_timed_closest;
-            }
-            if (timed_a) {
-                st.timed_shadow_rays += level_shadow;
-                ++n_timed_shadow;
-            }
+            if (timed_c) st.timed_closest_rays += L == 0 ? valid_pixels : n_level;
+            if (timed_a) st.timed_shadow_rays += level_shadow;
             if (n_level > 0) levels = L + 1;
-            if (n_work == 0) break;  // nothing to shade, nothing spawned
+            if (n_work == 0) {  // nothing to shade, nothing spawned
+                if (int rc = mark(CLS_OTHER)) return rc;
+                break;
+            }
             RayRec* next_rays = nullptr;
             uint32_t next_cap = 0;
             if (L + 1 < max_levels && spawn > 0) {
@@ -1422,18 +1440,14 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 next_cap = spawn;
             }
             const dim3 grid_s((n_work + 255) / 256);
-            const bool timed_s = n_timed_shade < kMaxTimed;
-            if (timed_s) { HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade], stream)); }
+            if (int rc = mark(CLS_SHADE)) return rc;
             hipLaunchKernelGGL(k_shade, grid_s, block, 0, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words,
                                lv.out.p, next_rays, next_cap, cnt);
             HIP_TRY(hipGetLastError());
-            if (timed_s) {
-                HIP_TRY(hipEventRecord(ev_shade[2 * n_timed_shade + 1], stream));
-                ++n_timed_shade;
-            }
             st.launches_shade++;
             cap = next_cap;
         }
+        if (int rc = mark(CLS_OTHER)) return rc;  // the resolve passes are not timed
         st.levels = std::max(st.levels, levels);
         for (uint32_t L = levels; L-- > 1;) {
             Level& lv = a->levels[L];
@@ -1472,17 +1486,12 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev_total[0], ev_total[1]));
     st.ms_total = ms;
-    for (int k = 0; k < n_timed_closest; ++k) {
-        HIP_TRY(hipEventElapsedTime(&ms, ev_closest[2 * k], ev_closest[2 * k + 1]));
-        st.ms_closest += ms;
-    }
-    for (int k = 0; k < n_timed_shade; ++k) {
-        HIP_TRY(hipEventElapsedTime(&ms, ev_shade[2 * k], ev_shade[2 * k + 1]));
-        st.ms_shade += ms;
-    }
-    for (int k = 0; k < n_timed_shadow; ++k) {
-        HIP_TRY(hipEventElapsedTime(&ms, ev_shadow[2 * k], ev_shadow[2 * k + 1]));
-        st.ms_shadow += ms;
+    for (int k = 0; k + 1 < n_marks; ++k) {
+        if (mark_cls[k] == CLS_OTHER) continue;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_mark[k], ev_mark[k + 1]));
+        if (mark_cls[k] == CLS_CLOSEST) st.ms_closest += ms;
+        else if (mark_cls[k] == CLS_SHADOW) st.ms_shadow += ms;
+        else st.ms_shade += ms;
     }
     st.secondary_rays = a->h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
     st.shadow_rays = a->h_totals->shadow_rays;
