@@ -159,6 +159,31 @@ def add_stats(acc, st):
     acc["closest_rays"] += st.timed_closest_rays
 
 
+def pmc_summary():
+    """The committed counter summary of the latest round (tools/pmc_profile.sh), or {}."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        return json.load(f).get("workloads", {}), "profiles/" + os.path.basename(files[-1])
+
+
+def memory_side(kernels, name, workload):
+    """Beyond-L2 traffic of the two traversal kernels from the counter summary, priced with this run's kernel times:
+    on a tree far larger than the L2 the per-lane any-hit pass is bound by scattered 64..128-byte reads, not by issue."""
+    pmc, src = pmc_summary()
+    for k in ("k_shadow", "k_closest"):
+        e = pmc.get(workload, {}).get("kernels", {}).get(k)
+        if not e or "bytes_per_launch" not in e or not kernels[k]["avg_launch_ms"]:
+            continue
+        gbps = e["bytes_per_launch"] / (kernels[k]["avg_launch_ms"] * 1e-3) / 1e9
+        kernels[k]["beyond_l2_GBps"] = gbps
+        kernels[k]["hbm_frac"] = gbps / HBM_PEAK_GBPS
+        kernels[k]["l2_hit_rate"] = e.get("l2_hit_rate")
+        kernels[k]["counters_source"] = src
+
+
 def run_other_workload(name, frames, rt, Scene, torch):
     """A few frames of another benchmark configuration on this GPU (device-resident frame buffer, one rank)."""
     wl = WORKLOADS[name]
@@ -181,10 +206,12 @@ def run_other_workload(name, frames, rt, Scene, torch):
     work = reference_work(ads, rt, wl)
     ts = ads.tree_stats()
     ks = kernel_summary(acc, frames, work)
+    memory_side(ks, name, name)
     res = {"Mrays_per_s": acc["rays"] / elapsed / 1e6, "ms_per_frame": elapsed / frames * 1e3, "frames": frames,
            "rays_per_frame": acc["rays"] // frames, "triangles": scene.n_triangles, "octree_nodes": ts["nodes"],
            "octree_build_s": round(ts["build_seconds"], 4), "reference_work_per_ray": work, "kernels": ks,
-           "k_shadow_frac": ks["k_shadow"].get("frac_of_fp32_vector_peak"), "k_closest_frac": ks["k_closest"].get("frac_of_fp32_vector_peak")}
+           "k_shadow_frac": ks["k_shadow"].get("frac_of_fp32_vector_peak"), "k_closest_frac": ks["k_closest"].get("frac_of_fp32_vector_peak"),
+           "k_shadow_hbm_frac": ks["k_shadow"].get("hbm_frac")}
     ads.close()
     del frame
     return res

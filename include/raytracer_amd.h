@@ -12,8 +12,15 @@
  *    RT_MEM_HOST (the library stages them) or RT_MEM_DEVICE (used in place;
  *    must belong to the handle's device).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *    Calls with device buffers are asynchronous on that stream unless they return
- *    counts; calls with host buffers return after the results are in the buffers.
+ *    rt_ads_trace_closest / rt_ads_trace_any with device buffers and rt_ads_search_noalloc are
+ *    asynchronous on that stream; with host buffers they return after the results are in the
+ *    buffers.  rt_render and rt_render_primary_hits are SYNCHRONOUS: they return after the frame
+ *    is complete on `stream` (the host follows the recursion levels through pinned memory the
+ *    kernels write, without synchronising the stream inside the frame, and synchronises once at
+ *    the end); their level buffers grow on demand, so the first frames of a size may allocate.
+ *    rt_ads_build, rt_ads_search, rt_scene_set_shading and rt_ads_export_tree run on the default
+ *    stream and return when done.  While rt_ads_collect_search_stats is on, every query call is
+ *    synchronous.
  *  - A handle is bound to one device and must be used from one host thread at a
  *    time, like the reference's Ads object (its counters are plain mutable fields,
  *    src/ADS/Octree/octree.h:55-61).

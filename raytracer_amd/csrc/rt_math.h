@@ -72,7 +72,10 @@ __device__ __forceinline__ float div_refined(float n, float d, float r1) {
 __device__ __forceinline__ f3 reciprocal3(f3 d, bool need) {
     const float lo = __builtin_fminf(__builtin_fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
     const float hi = __builtin_fmaxf(__builtin_fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    const bool in_range = lo >= kEps && hi <= kDivFastMax;  // the range rcp_refined is checked on (false for NaN)
+    // The range rcp_refined is checked on.  fminf / fmaxf drop a NaN operand, so a NaN component does not by itself
+    // force the true division; it does not need to: both forms return a NaN for that component, and no caller lets
+    // a reciprocal reach an output -- it only feeds comparisons, which a NaN fails whatever its sign and payload.
+    const bool in_range = lo >= kEps && hi <= kDivFastMax;
     if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) return f3{rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z)};
     return f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 }
@@ -85,7 +88,9 @@ RT_HD f3 div_guard(f3 a, float s) {
     const bool divides = fabsf(s) > kEps;
     const float lo = __builtin_fminf(__builtin_fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
     const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)), fabsf(s));
-    const bool in_range = lo >= kDivFastMin && hi <= kDivFastMax;  // (false for NaN operands)
+    // fminf / fmaxf drop NaN operands (see reciprocal3); a NaN component stays a NaN through either form, and a NaN
+    // divisor fails `divides`
+    const bool in_range = lo >= kDivFastMin && hi <= kDivFastMax;
     if (__builtin_amdgcn_ballot_w64(divides && !in_range) == 0) {
         const float r1 = div_refined_r1(s);
         return divides ? f3{div_refined(a.x, s, r1), div_refined(a.y, s, r1), div_refined(a.z, s, r1)} : f3{0.f, 0.f, 0.f};

@@ -9,6 +9,7 @@
 //    0 except shininess = ior = dissolve = 1.
 //  * write_ppm: the P3 text the reference writes (src/Renderer/renderer.cc:381-390, src/color.h:12-15).
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,18 +25,73 @@ namespace rt {
 
 namespace {
 
+// Decimal text -> double the way the reference's vendored parser does it (include/tiny_obj_loader.h:897-1028 of the
+// reference, tryParseDouble), NOT the correctly rounded strtod: integer digits accumulate as m = m * 10 + digit,
+// fraction digit k adds digit * 10^-k (a table for k < 8, pow(10, -k) beyond), a decimal exponent e is applied as
+// ldexp(m * 5^e, e).  The sums carry rounding errors, so a literal near a float rounding boundary can come out one ulp
+// away from strtod's value -- and one ulp in a vertex can move a triangle into or out of an octant.
+// Grammar: [sign] (digits | '.') ['.' digits] [('e' | 'E') [sign] digits]; returns false (value untouched) on anything else.
+bool parse_decimal(const char* s, const char* end, double* out) {
+    if (s >= end) return false;
+    auto digit = [](char ch) { return ch >= '0' && ch <= '9'; };
+    double m = 0.0;
+    bool negative = false, leading_dot = false;
+    const char* c = s;
+    if (*c == '+' || *c == '-') {
+        negative = *c == '-';
+        ++c;
+        leading_dot = c != end && *c == '.';
+    } else if (*c == '.') {
+        leading_dot = true;
+    } else if (!digit(*c)) {
+        return false;
+    }
+    if (!leading_dot) {
+        int n = 0;
+        for (; c != end && digit(*c); ++c, ++n) m = m * 10 + static_cast<int>(*c - '0');
+        if (n == 0) return false;
+    }
+    int e10 = 0;
+    if (c != end && *c == '.') {
+        static const double kTenth[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+        ++c;
+        for (int k = 1; c != end && digit(*c); ++c, ++k) m += static_cast<int>(*c - '0') * (k < 8 ? kTenth[k] : std::pow(10.0, -k));
+    }
+    if (c != end && (*c == 'e' || *c == 'E')) {
+        ++c;
+        bool e_negative = false;
+        if (c != end && (*c == '+' || *c == '-')) {
+            e_negative = *c == '-';
+            ++c;
+        } else if (c == end || !digit(*c)) {
+            return false;
+        }
+        int n = 0;
+        for (; c != end && digit(*c); ++c, ++n) {
+            if (e10 > 2147483647 / 10) return false;
+            e10 = e10 * 10 + static_cast<int>(*c - '0');
+        }
+        if (n == 0) return false;
+        if (e_negative) e10 = -e10;
+    }
+    const double v = e10 ? std::ldexp(m * std::pow(5.0, e10), e10) : m;
+    *out = negative ? -v : v;
+    return true;
+}
+
 struct Cursor {
     const char* p;
     void skip_blank() {
         while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
     }
     bool at_end() const { return *p == 0 || *p == '\n' || *p == '#'; }
-    float real() {
+    float real() {  // one blank-delimited token (tiny_obj_loader.h:1030-1038: parseReal, default 0)
         skip_blank();
-        char* e = nullptr;
-        const double v = std::strtod(p, &e);
-        if (e == p) return 0.0f;
-        p = e;
+        const char* end = p;
+        while (*end != 0 && *end != ' ' && *end != '\t' && *end != '\r' && *end != '\n') ++end;
+        double v = 0.0;
+        parse_decimal(p, end, &v);
+        p = end;
         return static_cast<float>(v);
     }
     bool integer(long& out) {
