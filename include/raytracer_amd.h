@@ -97,6 +97,11 @@ int rt_ads_build(rt_ads* ads, const float* positions, uint64_t n_triangles);
 int rt_ads_export_tree(const rt_ads* ads, void* node_records, void* leaf_slots, uint32_t* root_info2, uint64_t* n_records,
                        uint64_t* n_slots, uint32_t* max_stack, int* built_on_device);
 
+/* Which optional forms of the tree are resident beside the plain records (both serve the wave-together kernels and
+ * leave the candidate sets of octree.cc:186-191 unchanged): small_tree_triangles > 0 = the small-tree form (<= 32 leaves,
+ * <= 1024 triangles), clusters > 0 = the clustered form for any-hit rays.  Either pointer may be NULL. */
+int rt_ads_tree_forms(const rt_ads* ads, uint64_t* small_tree_triangles, uint32_t* clusters);
+
 /* Octree::PrintStats / calculate_stats, structural part (src/ADS/Octree/octree.cc:209-266). */
 typedef struct rt_tree_stats {
     uint64_t max_depth, nodes, leaves, max_triangles_in_leaf;
@@ -241,6 +246,15 @@ int rt_host_tree_sizes(const rt_host_tree* t, uint64_t* n_nodes, uint64_t* n_poo
 int rt_host_tree_export(const rt_host_tree* t, uint8_t* is_leaf, uint32_t* depth, float* bmin, float* bmax, int32_t* child8,
                         uint64_t* tri_begin, uint32_t* tri_count, uint32_t* pool);
 int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info2);
+/* The clustered form of the same tree, which the wave-together any-hit kernels walk on trees with more than 32 leaves
+ * (no reference counterpart: the candidates of Octree::Search, octree.cc:186-191, are unchanged -- it only lets a wave
+ * test a triangle once where several reached leaves list it).  Same record sizes and counts as rt_host_tree_export_flat.
+ * Node records: info[o][1] of an internal child carries 0x40000000 if that child roots a subtree of <= 32 leaves;
+ * info[o][0] of a leaf = first slot | ordinal << 24, the ordinal numbering (in slot order) the leaves of the leaf's
+ * cluster -- that subtree, or the leaf children of its parent above those subtrees.  Leaf slots: the first padding word
+ * = the set of the cluster's leaves (bit = ordinal) that list the slot's triangle.  *n_clusters = 0 and nothing
+ * written if the form does not apply (root leaf, no triangle listed twice in any cluster, >= 2^24 slots). */
+int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info1, uint32_t* n_clusters);
 int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out);
 
 /* ---- host-side scene input and image output (no GPU needed) ---------------------------------------------

@@ -68,11 +68,11 @@ class RenderStats(C.Structure):
 
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
-    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_stats",
+    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_forms", "rt_ads_tree_stats",
     "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_search_noalloc", "rt_ads_trace_closest", "rt_ads_trace_any",
     "rt_scene_set_shading", "rt_render", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
-    "rt_host_tree_export_flat", "rt_host_tree_stats",
+    "rt_host_tree_export_flat", "rt_host_tree_export_clustered", "rt_host_tree_stats",
     "rt_scene_load_obj", "rt_scene_data_free", "rt_scene_data_sizes", "rt_scene_data_export", "rt_write_ppm",
 ]
 
@@ -102,6 +102,7 @@ def lib():
     L.rt_ads_destroy.restype = None
     L.rt_ads_build.argtypes = [vp, vp, C.c_uint64]
     L.rt_ads_export_tree.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_ads_tree_forms.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
     L.rt_ads_reset_query_stats.argtypes = [vp]
@@ -119,6 +120,7 @@ def lib():
     L.rt_host_tree_sizes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4 + [C.POINTER(C.c_uint32)]
     L.rt_host_tree_export.argtypes = [vp] * 9
     L.rt_host_tree_export_flat.argtypes = [vp, vp, vp, vp]
+    L.rt_host_tree_export_clustered.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rt_host_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rt_scene_data_free.argtypes = [vp]

@@ -190,6 +190,12 @@ class GpuOctree(Ads):
         _capi.check(_capi.lib().rt_ads_export_tree(self._h, _p(nodes), _p(slots), root, None, None, None, None))
         return nodes, slots, (int(root[0]), int(root[1])), int(ms.value), bool(dev.value)
 
+    def tree_forms(self):
+        """(triangles of the small-tree form, clusters of the clustered form); 0 = that form is not resident."""
+        a, b = C.c_uint64(), C.c_uint32()
+        _capi.check(_capi.lib().rt_ads_tree_forms(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def tree_stats(self):
         st = _capi.TreeStats()
         _capi.check(_capi.lib().rt_ads_tree_stats(self._h, C.byref(st)))
@@ -267,6 +273,15 @@ class HostTree:
         root = np.zeros(2, np.uint32)
         _capi.check(_capi.lib().rt_host_tree_export_flat(self._h, _p(recs), _p(slots), _p(root)))
         return recs, slots, root
+
+    def export_clustered(self):
+        """The clustered form: (node records, leaf slots, root_info[1], number of subtree clusters), or None if the
+        form does not apply to this tree."""
+        recs = np.zeros(self.n_records, self.NODE_DT)
+        slots = np.zeros(self.n_slots, self.SLOT_DT)
+        r1, nc = C.c_uint32(), C.c_uint32()
+        _capi.check(_capi.lib().rt_host_tree_export_clustered(self._h, _p(recs), _p(slots), C.byref(r1), C.byref(nc)))
+        return (recs, slots, int(r1.value), int(nc.value)) if nc.value else None
 
     def stats(self):
         st = _capi.TreeStats()

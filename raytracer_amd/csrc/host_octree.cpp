@@ -312,6 +312,98 @@ bool flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
     return true;
 }
 
+void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, size_t n_slots, const uint32_t root_info[2], ClusterForm& out) {
+    out = ClusterForm();
+    if (n_rec == 0 || !(root_info[1] & kChildInternal) || n_slots > kClusterSlotMask) return;
+    // leaves below every internal node; records are in breadth-first order, so children follow their parents
+    std::vector<uint32_t> below(n_rec, 0);
+    for (size_t r = n_rec; r-- > 0;) {
+        uint64_t sum = 0;
+        for (int o = 0; o < 8; ++o) {
+            const uint32_t i0 = nodes[r].info[o][0], i1 = nodes[r].info[o][1];
+            if (i1 == 0) continue;
+            sum += (i1 & kChildInternal) ? below[i0] : 1u;
+        }
+        below[r] = (uint32_t)std::min<uint64_t>(sum, 0xffffffffu);
+    }
+    out.nodes.assign(nodes, nodes + n_rec);
+    out.slots.assign(slots, slots + n_slots);
+    out.root_info1 = root_info[1];
+    std::vector<uint32_t> roots;
+    if (below[root_info[0]] <= kClusterMaxLeaves) {
+        out.root_info1 |= kChildCluster;
+        roots.push_back(root_info[0]);
+    }
+    for (size_t r = 0; r < n_rec; ++r) {
+        if (below[r] <= kClusterMaxLeaves) continue;  // inside a cluster (or its root): its children are not roots
+        for (int o = 0; o < 8; ++o) {
+            const uint32_t i0 = nodes[r].info[o][0], i1 = nodes[r].info[o][1];
+            if ((i1 & kChildInternal) && below[i0] <= kClusterMaxLeaves) {
+                out.nodes[r].info[o][1] = i1 | kChildCluster;
+                roots.push_back(i0);
+            }
+        }
+    }
+    bool any_repeat = false;
+    std::vector<uint32_t> stack;
+    std::vector<std::pair<uint32_t, uint32_t>> leaves;  // (first slot, position of its info pair = record * 8 + octant)
+    std::vector<std::pair<uint32_t, uint32_t>> listed;  // (triangle, ordinal)
+    // numbers the leaves of one cluster in slot order (= breadth-first leaf order) and gives every slot its triangle's leaf set
+    auto annotate = [&]() {
+        std::sort(leaves.begin(), leaves.end());
+        listed.clear();
+        for (size_t k = 0; k < leaves.size(); ++k) {
+            const uint32_t r = leaves[k].second >> 3, o = leaves[k].second & 7u;
+            out.nodes[r].info[o][0] = leaves[k].first | ((uint32_t)k << kClusterOrdShift);
+            for (uint32_t j = 0; j < nodes[r].info[o][1]; ++j) listed.emplace_back(slots[leaves[k].first + j].tri, (uint32_t)k);
+        }
+        std::sort(listed.begin(), listed.end());
+        size_t a = 0;
+        while (a < listed.size()) {
+            size_t b = a;
+            uint32_t set = 0;
+            while (b < listed.size() && listed[b].first == listed[a].first) set |= 1u << listed[b++].second;
+            any_repeat = any_repeat || b - a > 1;
+            for (size_t k = a; k < b; ++k) {
+                const uint32_t leaf = listed[k].second;
+                const uint32_t r = leaves[leaf].second >> 3, o = leaves[leaf].second & 7u;
+                const uint32_t begin = leaves[leaf].first, count = nodes[r].info[o][1];
+                // leaf lists are ascending in triangle index
+                const LeafTri* lo = std::lower_bound(slots + begin, slots + begin + count, listed[a].first,
+                                                     [](const LeafTri& s, uint32_t tri) { return s.tri < tri; });
+                out.slots[(size_t)(lo - slots)].pad0 = set;
+            }
+            a = b;
+        }
+    };
+    for (const uint32_t root : roots) {  // a subtree
+        leaves.clear();
+        stack.assign(1, root);
+        while (!stack.empty()) {
+            const uint32_t r = stack.back();
+            stack.pop_back();
+            for (int o = 0; o < 8; ++o) {
+                const uint32_t i0 = nodes[r].info[o][0], i1 = nodes[r].info[o][1];
+                if (i1 == 0) continue;
+                if (i1 & kChildInternal) stack.push_back(i0);
+                else leaves.emplace_back(i0, r * 8u + (uint32_t)o);
+            }
+        }
+        annotate();
+    }
+    for (size_t r = 0; r < n_rec; ++r) {  // the leaf children of a node above the subtrees
+        if (below[r] <= kClusterMaxLeaves) continue;
+        leaves.clear();
+        for (int o = 0; o < 8; ++o) {
+            const uint32_t i0 = nodes[r].info[o][0], i1 = nodes[r].info[o][1];
+            if (i1 != 0 && !(i1 & kChildInternal)) leaves.emplace_back(i0, (uint32_t)r * 8u + (uint32_t)o);
+        }
+        if (!leaves.empty()) annotate();
+    }
+    out.n_clusters = any_repeat ? (uint32_t)std::max<size_t>(roots.size(), 1) : 0u;
+    if (out.n_clusters == 0) out = ClusterForm();
+}
+
 TreeShape tree_shape(const HostOctree& t) {
     TreeShape s;
     if (t.empty) return s;

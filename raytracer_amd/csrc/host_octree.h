@@ -53,6 +53,10 @@ static_assert(sizeof(LeafTri) == 48, "LeafTri must be 48 bytes");
 
 constexpr uint32_t kChildInternal = 0x80000000u;
 constexpr uint32_t kFlatMaxLeaves = 32, kFlatMaxTris = 1024;
+// Clustered form (see ClusterForm): flag of an internal child that is the root of a cluster, and where a cluster's leaf
+// keeps its ordinal inside info[0] (slot index below, ordinal above).
+constexpr uint32_t kChildCluster = 0x40000000u;
+constexpr uint32_t kClusterMaxLeaves = 32, kClusterOrdShift = 24, kClusterSlotMask = (1u << kClusterOrdShift) - 1u;
 
 // One internal node.  The boxes of its 8 octants share their planes: octant o = (bx<<2)|(by<<1)|bz has
 // min.x = lo[0][bx], max.x = hi[0][bx], min.y = lo[1][by], ... (octree.cc:93-97 computes every octant's corner from
@@ -82,6 +86,25 @@ struct FlatOctree {
     std::vector<NodeRec> flat_nodes;
     std::vector<LeafTri> flat_tris;
 };
+
+// Clustered form of a tree that is too big for the small-tree form.  The leaves are grouped into CLUSTERS: the leaves
+// of each maximal subtree with at most kClusterMaxLeaves leaves, and -- above those subtrees -- the leaf children of
+// each node.  For a cluster the wave-together any-hit walk first only records, per lane, which of the cluster's leaves
+// the lane reaches (one bit per leaf ordinal; ordinals follow the slot order) and then tests every triangle listed by
+// the reached leaves ONCE, for all lanes whose reached leaves list it -- instead of once per listing leaf (a wall
+// triangle of a Cornell box is listed by most of the root's octants).  nodes = the tree's records with
+// (a) kChildCluster set in info[1] of every internal child that is the root of such a subtree and (b) info[0] of every
+// leaf = slot index | ordinal << kClusterOrdShift; slots = the leaf slots with pad0 = the set of the cluster's leaves
+// (by ordinal) that list the slot's triangle.
+struct ClusterForm {
+    std::vector<NodeRec> nodes;
+    std::vector<LeafTri> slots;
+    uint32_t root_info1 = 0;  // root_info[1], with kChildCluster if the whole tree is one cluster
+    uint32_t n_clusters = 0;
+};
+// Fills `out` from the flattened tree; leaves it empty (n_clusters = 0) when the form does not apply: root leaf, no
+// cluster with a triangle listed twice, or slot indices that need more than kClusterOrdShift bits.
+void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, size_t n_slots, const uint32_t root_info[2], ClusterForm& out);
 
 struct TreeShape {
     uint64_t max_depth = 0, nodes = 0, leaves = 0, max_tris_in_leaf = 0, leaf_refs = 0, internal = 0;

@@ -118,6 +118,7 @@ struct SearchWork {
 
 constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
+constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots are walked by the wave together, whatever the rays
 
 // Launches KERNEL<cull, mode>(args...) for run-time cull / traversal mode.
 #define RT_LAUNCH_MODE(KERNEL, CULL, mode, grid, block, stream, ...)                                                \
@@ -140,6 +141,9 @@ void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t strea
     } else if (mode == MODE_LANE) {  // one-wave blocks
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_LANE, 1>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_CLUSTER) {
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_CLUSTER, 4>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_CLUSTER, 4>), grid, block, 0, stream, args...);
     } else {
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_WAVE, 4>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_WAVE, 4>), grid, block, 0, stream, args...);
@@ -197,6 +201,11 @@ struct rt_ads {
     DevBuf<NodeRec> d_nodes;
     DevBuf<LeafTri> d_slots, d_tri_geom, d_flat_tris;
     DevBuf<NodeRec> d_flat_nodes;
+    // clustered form (ClusterForm in host_octree.h): any-hit walks of trees that stay in the wave-together form
+    DevBuf<NodeRec> d_cl_nodes;
+    DevBuf<LeafTri> d_cl_slots;
+    uint32_t n_clusters = 0, cl_root_info1 = 0;
+    bool use_clusters = true;
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
     DevBuf<MatDev> d_mats;
@@ -234,6 +243,10 @@ DevOctree dev_tree(const rt_ads* a) {
     t.flat_nodes = a->d_flat_nodes.p;
     t.flat_tris = a->d_flat_tris.p;
     t.n_flat_tris = a->use_flat ? (uint32_t)a->n_flat_tris : 0u;
+    const bool clustered = a->use_clusters && a->n_clusters != 0;
+    t.cl_nodes = clustered ? a->d_cl_nodes.p : nullptr;
+    t.cl_slots = clustered ? a->d_cl_slots.p : nullptr;
+    t.cl_root_info1 = a->cl_root_info1;
     return t;
 }
 
@@ -245,12 +258,15 @@ DevOctree dev_tree(const rt_ads* a) {
 // million closest-hit and a quarter million any-hit rays).
 constexpr uint64_t kPoolMaxRaysClosest = 1u << 19, kPoolMaxRaysAny = 1u << 18;
 int traversal_mode(const rt_ads* a, bool coherent_primary, bool any_hit, uint64_t n_rays) {
-    if (a->traversal == 1 || a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
+    const bool small_tree = a->use_flat && a->n_flat_tris != 0;
+    // any-hit rays that the wave walks together take the clustered form when the tree has one and no small-tree form
+    const int wave = (any_hit && !small_tree && a->use_clusters && a->n_clusters != 0) ? MODE_CLUSTER : MODE_WAVE;
+    if (a->max_stack == 0) return MODE_WAVE;  // (a root-leaf tree has nothing to descend)
+    if (a->traversal == 1) return wave;
     const bool pool_ok = a->shape.max_tris_in_leaf < (1u << kPoolCountBits);
     if (a->traversal == 2) return MODE_LANE;
     if (a->traversal == 3) return pool_ok ? MODE_POOL : MODE_LANE;
-    const bool small_tree = a->use_flat && a->n_flat_tris != 0;
-    if (small_tree || a->n_slots < 32768 || coherent_primary) return MODE_WAVE;
+    if (small_tree || a->n_slots < kWaveFormMaxSlots || coherent_primary) return wave;
     return (pool_ok && n_rays < (any_hit ? kPoolMaxRaysAny : kPoolMaxRaysClosest)) ? MODE_POOL : MODE_LANE;
 }
 
@@ -266,7 +282,7 @@ uint32_t pool_sparse(const rt_ads* a, int mode, uint64_t n_rays, uint32_t max_gr
 // Threads per block of k_closest.  Its hit compaction costs one atomic per block and the whole block waits for its
 // slowest wave there: big blocks pay off where waves take similar, short times (small trees), not on big trees where
 // a wave over a finely tessellated region runs many times longer than its neighbours.
-uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE && a->n_slots < 32768) ? 1024u : 256u; }
+uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE && a->n_slots < kWaveFormMaxSlots) ? 1024u : 256u; }
 
 template <class... Args>
 void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
@@ -456,6 +472,17 @@ int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* le
     }
     return RT_OK;
 }
+int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info1, uint32_t* n_clusters) {
+    if (!t) return fail(RT_ERR_INVALID, "null argument");
+    ClusterForm cf;
+    if (!t->host.empty) cluster_octree(t->flat.nodes.data(), t->flat.nodes.size(), t->flat.slots.data(), t->flat.slots.size(), t->flat.root_info, cf);
+    if (n_clusters) *n_clusters = cf.n_clusters;
+    if (root_info1) *root_info1 = cf.root_info1;
+    if (cf.n_clusters == 0) return RT_OK;
+    if (node_records) memcpy(node_records, cf.nodes.data(), cf.nodes.size() * sizeof(NodeRec));
+    if (leaf_slots) memcpy(leaf_slots, cf.slots.data(), cf.slots.size() * sizeof(LeafTri));
+    return RT_OK;
+}
 int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out) {
     if (!t || !out) return fail(RT_ERR_INVALID, "null argument");
     const TreeShape s = tree_shape(t->host);
@@ -502,7 +529,7 @@ void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
     a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
-    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
+    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_slots.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
     for (auto& l : a->levels) l.release();
     a->search.release();
     a->d_qstats.release();
@@ -573,6 +600,31 @@ int host_build(rt_ads* a) {
         }
         HIP_TRY(hipMemcpy(a->d_tri_geom.p, g.data(), n * sizeof(LeafTri), hipMemcpyHostToDevice));
     }
+    return RT_OK;
+}
+
+// The clustered form of the resident tree (either builder's), for trees whose any-hit rays are walked by the wave
+// together: the records are read back, annotated on the host (cluster_octree) and uploaded beside the plain arrays.
+int make_cluster_form(rt_ads* a) {
+    a->n_clusters = 0;
+    a->cl_root_info1 = 0;
+    if (a->empty || a->n_rec == 0 || !(a->root_info[1] & kChildInternal)) return RT_OK;
+    if (a->traversal != 1 && a->n_slots >= kWaveFormMaxSlots) return RT_OK;  // its any-hit rays use the per-lane / pool forms
+    if (a->n_slots > kClusterSlotMask) return RT_OK;
+    std::vector<NodeRec> nodes(a->n_rec);
+    std::vector<LeafTri> slots(a->n_slots);
+    HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, nodes.size() * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, slots.size() * sizeof(LeafTri), hipMemcpyDeviceToHost));
+    ClusterForm cf;
+    cluster_octree(nodes.data(), nodes.size(), slots.data(), slots.size(), a->root_info, cf);
+    if (cf.n_clusters == 0) return RT_OK;
+    HIP_TRY(a->d_cl_nodes.reserve(cf.nodes.size()));
+    HIP_TRY(a->d_cl_slots.reserve(cf.slots.size() + 4));  // +4: triangle records are fetched in groups of 4
+    HIP_TRY(hipMemcpy(a->d_cl_nodes.p, cf.nodes.data(), cf.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(a->d_cl_slots.p, cf.slots.data(), cf.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(a->d_cl_slots.p + cf.slots.size(), 0, 4 * sizeof(LeafTri)));
+    a->n_clusters = cf.n_clusters;
+    a->cl_root_info1 = cf.root_info1;
     return RT_OK;
 }
 
@@ -790,7 +842,18 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
+    a->use_clusters = true;
+    if (const char* e = getenv("RT_DISABLE_CLUSTERS")) a->use_clusters = !(e[0] == '1');
+    if (int rc = make_cluster_form(a)) return rc;
     a->built = true;
+    return RT_OK;
+}
+
+int rt_ads_tree_forms(const rt_ads* a, uint64_t* small_tree_triangles, uint32_t* clusters) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (small_tree_triangles) *small_tree_triangles = a->use_flat ? a->n_flat_tris : 0;
+    if (clusters) *clusters = a->use_clusters ? a->n_clusters : 0u;
     return RT_OK;
 }
 
@@ -1066,7 +1129,12 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     const int mode = traversal_mode(a, false, true, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
-    RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+    if (mode == MODE_CLUSTER) {
+        if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER>), grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+        else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER>), grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+    } else {
+        RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+    }
     HIP_TRY(hipGetLastError());
     if (a->collect_stats) {
         if (int rc = stats_begin(a, stream)) return rc;
@@ -1391,9 +1459,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 // light per pass (a narrower bundle of rays).
                 const int mode_a = traversal_mode(a, false, true, (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle);
                 gshift = 0;
-                while (mode_a != MODE_WAVE && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
+                const bool wave_a = mode_a == MODE_WAVE || mode_a == MODE_CLUSTER;
+                while (!wave_a && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
-                const dim3 block_a(mode_a == MODE_WAVE ? 256 : 64);
+                const dim3 block_a(wave_a ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
                 launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
@@ -1568,7 +1637,8 @@ extern "C" int rt_debug_lane_profile(unsigned long long* out32) {  // 48 values
     }
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     unsigned long long z[16] = {0};
-    for (int i = 16; i < 32; ++i) out32[i] = 0;
+    if (hipMemcpyFromSymbol(out32 + 16, HIP_SYMBOL(rt::g_wave_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wave_prof), z, sizeof z) != hipSuccess) return 1;
     return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof z) != hipSuccess;
 }
 #endif

@@ -47,8 +47,10 @@ namespace rt {
 
 // How a kernel walks the tree.  MODE_WAVE: the wave together (rt_traverse.h); MODE_LANE: every lane its own ray
 // (rt_traverse_lane.h); MODE_POOL: the rays of a wave share a pool of descent tasks (rt_traverse_pool.h).  The
-// per-wave stacks of the last two are in LDS; a kernel declares one slot per wave of its block.
-enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_POOL = 2 };
+// per-wave stacks of the last two are in LDS; a kernel declares one slot per wave of its block.  MODE_CLUSTER: the wave
+// together over the clustered form of the tree (any-hit kernels only; a kernel of its own so that its extra registers
+// do not cost the other wave-together kernels their occupancy).
+enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_POOL = 2, MODE_CLUSTER = 3 };
 template <int MODE>
 struct TraverseLds {
     uint32_t unused;
@@ -73,7 +75,10 @@ template <bool ANY, bool CULL, int MODE>
 __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
-    else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
+    else if constexpr (MODE == MODE_CLUSTER) {
+        static_assert(ANY, "the clustered form serves any-hit queries");
+        traverse_any_clustered<CULL>(T, valid, o, d, t_limit, h);
+    } else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
 }
 
 struct alignas(16) TriShade {  // per triangle in Build order

@@ -43,6 +43,10 @@ struct DevOctree {
     const NodeRec* flat_nodes;
     const LeafTri* flat_tris;
     uint32_t n_flat_tris;
+    // Clustered form (cl_nodes != nullptr; any-hit walks of mid-size trees): see ClusterForm in host_octree.h.
+    const NodeRec* cl_nodes;
+    const LeafTri* cl_slots;
+    uint32_t cl_root_info1;
 };
 
 typedef const RT_CONST float* cfloat_p;
@@ -111,6 +115,16 @@ __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, floa
     return t_max >= t_min;
 }
 
+#ifdef RT_LANE_PROFILE
+// Any-hit walks of the wave-together forms.  Plain walk: 0 waves, 1 node visits, 2 leaf visits, 3 triangle tests started.
+// Clustered walk: 8 waves, 9 node visits, 10 cluster visits, 11 leaves reached, 12 slots scanned, 13 of them skipped
+// (tested at an earlier leaf), 14 of them needed by no lane, 15 triangle tests started, 7 tests of leaves outside clusters.
+__device__ unsigned long long g_wave_prof[16];
+#define RT_WPROF(k, v) do { if (__lane_id() == 0) atomicAdd(&g_wave_prof[k], (unsigned long long)(v)); } while (0)
+#else
+#define RT_WPROF(k, v) do { } while (0)
+#endif
+
 struct HitState {
     float t;         // closest: best t so far (+inf = none)
     uint32_t slot;   // closest: global leaf slot of the winner (small-tree form: ordinal of its first reached leaf)
@@ -144,6 +158,7 @@ template <bool ANY, bool CULL>
 __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32_t slot, lanemask mine, f3 o, f3 d, float t_limit,
                                          HitState& h) {
     if (mine == 0) return;
+    if (ANY) RT_WPROF(3, 1);
     const f3 a = mk(RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2));
     const f3 e1 = mk(RT_F(blk, 12 * j + 3), RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5));
     const f3 e2 = mk(RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8));
@@ -263,6 +278,37 @@ struct WaveStack {
     }
 };
 
+// The slab products of one node for one ray, per axis and per half (octant bit 0 / 1): collision_detection.h:77-81,
+// already ordered by the sign of inv.  pl = the 12 planes of a NodeRec (lo[3][2], hi[3][2]).
+struct SlabSides {
+    float tn[3][2], tf[3][2];
+};
+__device__ __forceinline__ void slab_sides(const u32x16& pl, f3 o, f3 inv, SlabSides& s) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float oo = comp(o, ax), ii = comp(inv, ax);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float t0 = (__uint_as_float(pl[ax * 2 + b]) - oo) * ii;
+            float t1 = (__uint_as_float(pl[6 + ax * 2 + b]) - oo) * ii;
+            if (ii < 0.0f) { const float sw = t0; t0 = t1; t1 = sw; }
+            s.tn[ax][b] = t0;
+            s.tf[ax][b] = t1;
+        }
+    }
+}
+// collision_detection.h:72-85 for octant c in its order: x, then y, then z, folded into the running max / min from
+// -inf / +inf.
+__device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c) {
+    const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+    float t_min = slab_max(-RT_INF, s.tn[0][bx]), t_max = slab_min(RT_INF, s.tf[0][bx]);
+    t_min = slab_max(t_min, s.tn[1][by]);
+    t_max = slab_min(t_max, s.tf[1][by]);
+    t_min = slab_max(t_min, s.tn[2][bz]);
+    t_max = slab_min(t_max, s.tf[2][bz]);
+    return t_max >= t_min;
+}
+
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
 template <bool ANY, bool CULL, bool FLAT>
 __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
@@ -272,44 +318,27 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);
     uint32_t i0 = T.root_info0, i1 = T.root_info1;
     lanemask mine = all;
+    if (ANY && !FLAT) RT_WPROF(0, 1);
     for (;;) {
         if (i1 & kChildInternal) {
+            if (ANY && !FLAT) RT_WPROF(1, 1);
             // one round trip for the node: 12 planes (+ the non-empty mask) and the 8 info pairs (NodeRec, 32 dwords)
             cu32_p rec = nodes + (size_t)i0 * 32;
             const u32x16 pl = sload16(rec);
             const u32x16 info = sload16(rec + 16);  // dwords 16..31 = info[8][2]
-            // Per axis and per half (octant bit 0 / 1): the slab products of collision_detection.h:77-81,
-            // already ordered by the sign of inv, and folded into the running max / min from -inf / +inf.
-            float tn[3][2], tf[3][2];
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const float oo = comp(o, ax), ii = comp(inv, ax);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float t0 = (__uint_as_float(pl[ax * 2 + b]) - oo) * ii;
-                    float t1 = (__uint_as_float(pl[6 + ax * 2 + b]) - oo) * ii;
-                    if (ii < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
-                    tn[ax][b] = t0;
-                    tf[ax][b] = t1;
-                }
-            }
+            SlabSides sl;
+            slab_sides(pl, o, inv, sl);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t c1 = info[2 * c + 1];
                 if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
-                const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-                // collision_detection.h:72-85 in its order: x, then y, then z
-                float t_min = slab_max(-RT_INF, tn[0][bx]), t_max = slab_min(RT_INF, tf[0][bx]);
-                t_min = slab_max(t_min, tn[1][by]);
-                t_max = slab_min(t_max, tf[1][by]);
-                t_min = slab_max(t_min, tn[2][bz]);
-                t_max = slab_min(t_max, tf[2][bz]);
-                const lanemask pm = mine & ballot64(t_max >= t_min);
+                const lanemask pm = mine & ballot64(octant_passes(sl, c));
                 if (pm == 0) continue;
                 if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;
                 else st.push(info[2 * c], c1, pm);
             }
         } else {
+            if (ANY && !FLAT) RT_WPROF(2, 1);
             leaf_tests<ANY, CULL>(T, i0, i1, mine, o, d, t_limit, h);
         }
         // next entry that still has a live lane
@@ -327,6 +356,120 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     if (FLAT) flat_tests<ANY, CULL>(T, all, reach, o, d, t_limit, h);
 }
 
+// One slot of a reached leaf in the test phase of a cluster (record jj of the 4-record block).  lm = the cluster's
+// leaves that list the slot's triangle; `earlier` = the leaves the wave reached before this one: a triangle that one of
+// them lists has been tested there, for every lane that needs it.
+template <bool CULL>
+__device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, bool in_leaf, uint32_t earlier, lanemask alive, uint32_t reach,
+                                            f3 o, f3 d, float t_limit, HitState& h) {
+    const uint32_t lm = RT_W(blk, 12 * jj + 10);
+    if (!in_leaf) return;
+    RT_WPROF(12, 1);
+    if ((lm & earlier) != 0) {
+        RT_WPROF(13, 1);
+        return;
+    }
+    const lanemask need = alive & ballot64((reach & lm) != 0);
+    if (need == 0) {
+        RT_WPROF(14, 1);
+        return;
+    }
+    RT_WPROF(15, 1);
+    const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
+    const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
+    const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
+    float t = RT_INF;
+    const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
+    if (hit == 0) return;
+    h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
+}
+
+// Any-hit walk over the clustered form.  Leaves are never pushed: the lanes that reach leaf k of the current cluster
+// set bit k of `reach`, the wave sets bit k of `wreach` and keeps the leaf's (first slot, count) in lane k of two
+// registers.  A cluster made of a node's leaf children is complete after that node's visit; a subtree cluster once the
+// stack is back at its height of the moment its root was visited.  Then the reached leaves are scanned in slot order and
+// each triangle is tested once, at the first reached leaf that lists it, for all lanes that reach any leaf listing it.
+// The candidate set of every ray is the one of the plain walk -- only the number of times the wave tests a triangle
+// changes -- so the answers are the same.
+template <bool CULL>
+__device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
+    const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
+    WaveStack st;
+    cu32_p nodes = as_const_u(T.cl_nodes);
+    cu32_p slots = as_const_u(T.cl_slots);
+    uint32_t i0 = T.root_info0, i1 = T.cl_root_info1;
+    lanemask mine = all;
+    int cl_base = -1;  // stack height at the visit of a subtree cluster's root; -1 outside those
+    uint32_t reach = 0, wreach = 0;
+    int leaf_begin = 0, leaf_count = 0;  // lane k: leaf k of the cluster
+    RT_WPROF(8, 1);
+    for (;;) {  // (i0, i1) is an internal node: only those are pushed
+        RT_WPROF(9, 1);
+        if (cl_base < 0) {
+            reach = 0;
+            wreach = 0;
+            if (i1 & kChildCluster) {
+                RT_WPROF(10, 1);
+                cl_base = st.sp;
+            }
+        }
+        cu32_p rec = nodes + (size_t)i0 * 32;
+        const u32x16 pl = sload16(rec);
+        const u32x16 info = sload16(rec + 16);
+        SlabSides sl;
+        slab_sides(pl, o, inv, sl);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t c1 = info[2 * c + 1];
+            if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
+            const lanemask pm = mine & ballot64(octant_passes(sl, c));
+            if (pm == 0) continue;
+            if (c1 & kChildInternal) {
+                st.push(info[2 * c], c1, pm);
+            } else {
+                const uint32_t ord = info[2 * c] >> kClusterOrdShift, bit = 1u << ord;
+                reach |= lane_of(pm) ? bit : 0u;
+                wreach |= bit;
+                RT_WPROF(11, 1);
+                leaf_begin = write_lane((int)(info[2 * c] & kClusterSlotMask), (int)ord, leaf_begin);
+                leaf_count = write_lane((int)c1, (int)ord, leaf_count);
+            }
+        }
+        // next node that still has a live lane; a cluster whose walk is complete is tested first
+        bool got = false;
+        for (;;) {
+            if (cl_base < 0 || st.sp == cl_base) {
+                cl_base = -1;
+                uint32_t w = wreach;
+                wreach = 0;
+                const uint32_t reached = w;
+                while (w != 0 && (all & ~h.found) != 0) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(w);
+                    const uint32_t earlier = reached & ((1u << k) - 1u);
+                    w &= w - 1u;
+                    const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane(leaf_begin, (int)k);
+                    const uint32_t count = (uint32_t)__builtin_amdgcn_readlane(leaf_count, (int)k);
+                    for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
+                        const Block48 blk = sload48(slots + (size_t)(begin + k0) * 12);
+                        cluster_one<CULL>(blk, 0, true, earlier, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 1, k0 + 1 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 2, k0 + 2 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 3, k0 + 3 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
+                    }
+                }
+            }
+            if (st.sp == 0) break;
+            st.pop(i0, i1, mine);
+            mine &= ~h.found;
+            if (mine != 0) {
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+    }
+}
+
 template <bool ANY, bool CULL>
 __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
@@ -339,6 +482,18 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     // traverse_impl handles it as a leaf entry.
     if (T.n_flat_tris) traverse_impl<ANY, CULL, true>(T, all, o, d, t_limit, h);
     else traverse_impl<ANY, CULL, false>(T, all, o, d, t_limit, h);
+}
+
+// Any-hit query over the clustered form (T.cl_nodes must be set; the host launches this only for such trees).
+template <bool CULL>
+__device__ __forceinline__ void traverse_any_clustered(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    h.t = RT_INF;
+    h.slot = 0xffffffffu;
+    h.tri = 0xffffffffu;
+    h.found = 0;
+    const lanemask all = ballot64(valid);
+    if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
+    traverse_clustered<CULL>(T, all, o, d, t_limit, h);
 }
 
 }  // namespace rt

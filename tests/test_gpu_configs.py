@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 FORMS = {
     "auto": {},
-    "general": {"RT_DISABLE_SMALL_TREE": "1"},
+    "general": {"RT_DISABLE_SMALL_TREE": "1"},                              # any-hit rays: the clustered form
+    "plain": {"RT_DISABLE_SMALL_TREE": "1", "RT_DISABLE_CLUSTERS": "1"},
     "lane": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"},
     "pool": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"},
 }
@@ -30,7 +31,7 @@ def bits(a):
 
 def build(rt, sc, monkeypatch=None, form="auto", builder="auto"):
     if monkeypatch is not None:
-        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL"):
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in FORMS[form].items():
             monkeypatch.setenv(k, v)
@@ -92,7 +93,7 @@ def test_sphere_spp4_spt32_against_the_oracle(rt, orc, scenes, monkeypatch, w, h
     kw = dict(fov=0.6, width=w, height=h, spp=4, spt=32, render_type="blinn_phong", shading="smooth", max_depth=10, **CAMERAS["sphere"])
     ref, ref_tri, ref_t, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, aspect_mode=aspect, **kw))
     first = None
-    for form in ("auto", "lane", "pool"):
+    for form in ("auto", "plain", "lane", "pool"):
         g = build(rt, sc, monkeypatch, form)
         cfg = rt.make_render_config(aspect_mode=aspect, **kw)
         img, st = g.render(cfg)
@@ -120,10 +121,11 @@ def test_sphere_spp4_spt32_full_size_properties(rt, orc, scenes, monkeypatch):
     # rows 536..543 against the oracle
     ref, _, _, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(536, 544), **kw), want_hits=False)
     assert np.abs(full[536:544] - ref[536:544]).max() <= 1.0 / 255.0
-    # the per-lane form on the same frame
-    g2 = build(rt, sc, monkeypatch, "lane")
-    img2, s2 = g2.render(cfg)
-    assert np.array_equal(bits(img2), bits(full)) and s2.rays == st.rays
+    # the per-lane form and the plain wave-together walk on the same frame
+    for other in ("lane", "plain"):
+        g2 = build(rt, sc, monkeypatch, other)
+        img2, s2 = g2.render(cfg)
+        assert np.array_equal(bits(img2), bits(full)) and s2.rays == st.rays, other
     # 4 ranks' bands
     out = np.zeros_like(full)
     rays = 0

@@ -168,6 +168,70 @@ def test_small_tree_form_equals_general_form(rt, orc, scenes, monkeypatch):
     assert len(verts) > 0
 
 
+@pytest.mark.parametrize("scene,mb,md", [("sphere", 16, 10), ("sphere", 4, 3), ("sphere", 2, 12), ("original", 16, 10), ("original", 1, 6),
+                                         ("synthetic5", 16, 10), ("soup", 8, 6)])
+def test_clustered_any_hit_form(rt, orc, scenes, monkeypatch, scene, mb, md):
+    """Any-hit rays that the wave walks together use the clustered form of the tree (a triangle listed by several
+    reached leaves of a cluster is tested once).  Its flags must equal the plain walk's and the oracle's: coherent and
+    random segments, both culling modes, NaN / inf / zero components, segments ending on the first surface, and a
+    rendered frame with area lights."""
+    if scene == "synthetic5":
+        sc = synthetic_scene(5)  # 20,514 triangles; RT_TRAVERSAL=wave keeps its any-hit rays in the wave-together form
+        sc = orc.Scene.from_arrays(sc.pos, None, sc.matid, sc.materials)
+    elif scene == "soup":
+        rs = np.random.RandomState(21)
+        c = rs.rand(3000, 1, 3).astype(np.float32) * 100
+        pos = (c + rs.randn(3000, 3, 3).astype(np.float32) * rs.choice([0.5, 4.0, 30.0], (3000, 1, 1)).astype(np.float32)).astype(np.float32)
+        pos[100:110] = pos[90:100]  # exact duplicates
+        base = scenes["original"]
+        sc = orc.Scene.from_arrays(pos, None, np.zeros(3000, np.int32), base.materials)
+    else:
+        sc = scenes[scene]
+    monkeypatch.setenv("RT_TRAVERSAL", "wave")
+    monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    monkeypatch.setenv("RT_DISABLE_CLUSTERS", "1")
+    g_plain = build(rt, sc, mb, md)
+    assert g_plain.tree_forms() == (0, 0)
+    monkeypatch.delenv("RT_DISABLE_CLUSTERS")
+    g = build(rt, sc, mb, md)
+    assert g.tree_forms()[0] == 0 and g.tree_forms()[1] > 0
+    ot = orc.Octree(sc, mb, md)
+    o, d = random_rays(sc, 40000, 23)
+    t_ref, tri_ref = ot.trace_closest(o, d, False)
+    hit = tri_ref >= 0
+    assert hit.sum() > 5000
+    rs = np.random.RandomState(6)
+    P = (o[hit] + d[hit] * t_ref[hit, None]).astype(np.float32)
+    lo, hi = sc.pos.reshape(-1, 3).min(0), sc.pos.reshape(-1, 3).max(0)
+    target = (lo + (hi - lo) * np.array([0.5, 0.95, 0.5], np.float32) + rs.randn(len(P), 3) * 0.02 * (hi - lo)).astype(np.float32)
+    cases = [(P, target),                                     # from surfaces towards one region: coherent, like shadow rays
+             (o[hit], P),                                     # segments that end on the first surface they meet
+             (o, (o + d * rs.rand(len(o), 1) * np.linalg.norm(hi - lo)).astype(np.float32))]  # random segments
+    with np.errstate(all="ignore"):
+        special = np.array([0.0, -0.0, 1e-40, 1e30, -1e30, np.inf, -np.inf, np.nan], np.float32)
+        Ps, Ls = P[:4096].copy(), target[:4096].copy()
+        for i in range(0, len(Ps), 3):
+            (Ps if i % 2 else Ls)[i, rs.randint(3)] = special[rs.randint(len(special))]
+        cases.append((Ps, Ls))
+        for Pc, Lc in cases:
+            for n in (len(Pc), 65, 1):
+                for cull in (True, False):
+                    ref = ot.trace_any(Pc[:n], Lc[:n], cull)
+                    assert np.array_equal(g.trace_any(Pc[:n], Lc[:n], cull), ref)
+                    assert np.array_equal(g_plain.trace_any(Pc[:n], Lc[:n], cull), ref)
+        occ = ot.trace_any(cases[0][0], cases[0][1], True)
+        assert 0 < occ.sum() < occ.size
+    if scene in ("sphere", "original"):
+        kw = dict(fov=0.6, width=64, height=48, spt=5, render_type="blinn_phong", shading="smooth" if sc.has_normals else "flat",
+                  aspect_mode=1, **CAMERAS[scene])
+        cfg = rt.make_render_config(**kw)
+        img, st = g.render(cfg)
+        img_p, st_p = g_plain.render(cfg)
+        assert np.array_equal(bits(img), bits(img_p)) and st.rays == st_p.rays and st.shadow_rays > 0
+        ref, _, _, ost = orc.render(sc, ot, orc.make_cfg(rng_mode=orc.RNG_COUNTER, **{**kw, "aspect_mode": orc.ASPECT_TRUE}), want_hits=False)
+        assert np.abs(img - ref).max() <= 1.0 / 255.0 and st.rays == ost.search_calls
+
+
 @pytest.mark.parametrize("mode", ["wave", "lane", "pool"])
 @pytest.mark.parametrize("scene,mb,md", [("sphere", 16, 10), ("sphere", 4, 3), ("original", 8, 2), ("original", 1000, 10)])
 def test_both_traversals(rt, orc, scenes, monkeypatch, mode, scene, mb, md):

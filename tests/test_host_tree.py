@@ -72,6 +72,71 @@ def test_flat_layout(scenes, scene, mb, md):
     assert ht.max_stack <= 128
 
 
+@pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3), ("sphere", 2, 12), ("original", 1, 6)])
+def test_clustered_layout(scenes, scene, mb, md):
+    """The clustered form is a re-labelling of the flat layout: same planes and links, every leaf in exactly one cluster
+    (a subtree of <= 32 leaves, or the leaf children of a node above those) with ordinals in slot order, and every
+    slot's mask = the leaves of its cluster that list its triangle."""
+    sc = scenes[scene]
+    ht = HostTree(sc.pos, mb, md)
+    recs, slots, root = ht.export_flat()
+    cl = ht.export_clustered()
+    INTERNAL, CLUSTER = 0x80000000, 0x40000000
+    n = len(recs)
+    below = np.zeros(n, np.int64)
+    for r in range(n - 1, -1, -1):
+        for o in range(8):
+            i0, i1 = int(recs[r]["info"][o, 0]), int(recs[r]["info"][o, 1])
+            if i1:
+                below[r] += below[i0] if i1 & INTERNAL else 1
+    if cl is None:
+        # allowed only when no cluster lists a triangle twice; with these scenes every tree has such a cluster
+        assert n == 0
+        return
+    crecs, cslots, croot1, n_sub = cl
+    assert same_bits(crecs["lo"], recs["lo"]) and same_bits(crecs["hi"], recs["hi"]) and same_bits(crecs["nonempty"], recs["nonempty"])
+    for k in ("a", "e1", "e2", "tri"):
+        assert same_bits(cslots[k], slots[k])
+    assert (croot1 & ~CLUSTER) == int(root[1]) and bool(croot1 & CLUSTER) == (below[0] <= 32)
+    # clusters: key -> list of (first slot, count, ordinal)
+    clusters = {}
+
+    def walk(r, key):
+        for o in range(8):
+            i0, i1 = int(recs[r]["info"][o, 0]), int(recs[r]["info"][o, 1])
+            c0, c1 = int(crecs[r]["info"][o, 0]), int(crecs[r]["info"][o, 1])
+            if i1 == 0:
+                assert c1 == 0
+            elif i1 & INTERNAL:
+                assert c0 == i0 and (c1 & ~CLUSTER) == i1
+                is_root = key is None and below[i0] <= 32
+                assert bool(c1 & CLUSTER) == is_root
+                walk(i0, ("sub", i0) if is_root else key)
+            else:
+                assert c1 == i1 and (c0 & 0xffffff) == i0
+                clusters.setdefault(key if key is not None else ("own", r), []).append((i0, i1, c0 >> 24))
+
+    walk(0, ("sub", 0) if below[0] <= 32 else None)
+    assert sum(len(v) for v in clusters.values()) == int((recs["info"][:, :, 1] != 0).sum() - (recs["info"][:, :, 1] & INTERNAL != 0).sum())
+    assert len([k for k in clusters if k[0] == "sub"]) == n_sub
+    seen = np.zeros(len(slots), bool)
+    repeats = 0
+    for key, leaves in clusters.items():
+        leaves.sort()
+        assert [l[2] for l in leaves] == list(range(len(leaves))) and len(leaves) <= 32  # ordinals follow the slot order
+        listed = {}
+        for b, c, k in leaves:
+            for t in slots["tri"][b:b + c]:
+                listed[int(t)] = listed.get(int(t), 0) | (1 << k)
+        for b, c, k in leaves:
+            for j in range(b, b + c):
+                assert int(cslots["pad"][j, 0]) == listed[int(slots["tri"][j])] and int(cslots["pad"][j, 1]) == 0
+                assert not seen[j]
+                seen[j] = True
+        repeats += sum(1 for m in listed.values() if m & (m - 1))
+    assert seen.all() and repeats > 0
+
+
 def test_synthetic_tree_equals_oracle_and_reference(orc):
     """Icosphere-in-Cornell-box scene: level 5 (20,514 triangles) node-for-node against the oracle; level 8
     (1,310,754 triangles) against the tree shape the reference binary printed (tests/golden/ref_kats.json S8)."""

@@ -49,3 +49,10 @@ for k, name in ((0, "closest"), (1, "any-hit")):
     print(f"pool {name}: waves {waves}  cycles/wave node steps {a / waves:.0f} leaf {b / waves:.0f} | per wave: node steps {steps / waves:.1f} "
           f"(tasks per step {tasks / max(steps, 1):.1f}) leaf phases {phases / waves:.1f} chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
           f"| cycles per node step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
+w = [int(out[16 + i]) for i in range(16)]
+if w[0]:
+    print(f"wave any-hit, plain walk: waves {w[0]}  per wave: node visits {w[1] / w[0]:.2f} leaf visits {w[2] / w[0]:.2f} triangle tests started {w[3] / w[0]:.2f}")
+if w[8]:
+    print(f"wave any-hit, clustered walk: waves {w[8]}  per wave: node visits {w[9] / w[8]:.2f} cluster visits {w[10] / w[8]:.2f} leaves reached {w[11] / w[8]:.2f} "
+          f"slots scanned {w[12] / w[8]:.2f} (tested earlier {w[13] / w[8]:.2f}, needed by no lane {w[14] / w[8]:.2f}) triangle tests started {w[15] / w[8]:.2f} "
+          f"+ outside clusters {w[3] / w[8]:.2f}")
