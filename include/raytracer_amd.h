@@ -248,13 +248,19 @@ int rt_host_tree_export(const rt_host_tree* t, uint8_t* is_leaf, uint32_t* depth
 int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info2);
 /* The clustered form of the same tree, which the wave-together any-hit kernels walk on trees with more than 32 leaves
  * (no reference counterpart: the candidates of Octree::Search, octree.cc:186-191, are unchanged -- it only lets a wave
- * test a triangle once where several reached leaves list it).  Same record sizes and counts as rt_host_tree_export_flat.
- * Node records: info[o][1] of an internal child carries 0x40000000 if that child roots a subtree of <= 32 leaves;
- * info[o][0] of a leaf = first slot | ordinal << 24, the ordinal numbering (in slot order) the leaves of the leaf's
- * cluster -- that subtree, or the leaf children of its parent above those subtrees.  Leaf slots: the first padding word
- * = the set of the cluster's leaves (bit = ordinal) that list the slot's triangle.  *n_clusters = 0 and nothing
- * written if the form does not apply (root leaf, no triangle listed twice in any cluster, >= 2^24 slots). */
-int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info1, uint32_t* n_clusters);
+ * test a triangle once where several reached leaves list it).  Leaves are grouped into clusters: the leaves of each
+ * maximal subtree with <= 32 leaves, and above those subtrees the leaf children of each node.
+ * node_records (as many as rt_host_tree_export_flat writes): info[o][1] of an internal child carries 0x40000000 if
+ * that child roots such a subtree; info[o][0] of a leaf = first slot | ordinal << 24, the ordinal numbering the leaves
+ * of its cluster in slot order; the first two padding words of the record that owns a cluster (the subtree's root, or
+ * the parent of the leaf children) = first record and record count of the cluster's list in cluster_triangles.
+ * cluster_triangles (48-byte leaf-slot records, *n_cluster_triangles of them): per cluster its distinct triangles in
+ * ascending index, first padding word = the set of the cluster's leaves (bit = ordinal) that list the triangle; every
+ * list is padded to a multiple of 4 records with all-zero records.  Call once with NULL arrays for the count.
+ * *n_clusters = 0 and nothing written if the form does not apply (root leaf, no triangle listed twice in any cluster,
+ * >= 2^24 slots). */
+int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* cluster_triangles, uint64_t* n_cluster_triangles,
+                                  uint32_t* root_info1, uint32_t* n_clusters);
 int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out);
 
 /* ---- host-side scene input and image output (no GPU needed) ---------------------------------------------

@@ -120,7 +120,7 @@ def lib():
     L.rt_host_tree_sizes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4 + [C.POINTER(C.c_uint32)]
     L.rt_host_tree_export.argtypes = [vp] * 9
     L.rt_host_tree_export_flat.argtypes = [vp, vp, vp, vp]
-    L.rt_host_tree_export_clustered.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rt_host_tree_export_clustered.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rt_host_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rt_scene_data_free.argtypes = [vp]

@@ -275,13 +275,16 @@ class HostTree:
         return recs, slots, root
 
     def export_clustered(self):
-        """The clustered form: (node records, leaf slots, root_info[1], number of subtree clusters), or None if the
-        form does not apply to this tree."""
+        """The clustered form: (node records, cluster triangle lists, root_info[1], number of subtree clusters), or
+        None if the form does not apply to this tree."""
+        r1, nc, nt = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _capi.check(_capi.lib().rt_host_tree_export_clustered(self._h, None, None, C.byref(nt), C.byref(r1), C.byref(nc)))
+        if not nc.value:
+            return None
         recs = np.zeros(self.n_records, self.NODE_DT)
-        slots = np.zeros(self.n_slots, self.SLOT_DT)
-        r1, nc = C.c_uint32(), C.c_uint32()
-        _capi.check(_capi.lib().rt_host_tree_export_clustered(self._h, _p(recs), _p(slots), C.byref(r1), C.byref(nc)))
-        return (recs, slots, int(r1.value), int(nc.value)) if nc.value else None
+        tris = np.zeros(nt.value, self.SLOT_DT)
+        _capi.check(_capi.lib().rt_host_tree_export_clustered(self._h, _p(recs), _p(tris), None, None, None))
+        return recs, tris, int(r1.value), int(nc.value)
 
     def stats(self):
         st = _capi.TreeStats()

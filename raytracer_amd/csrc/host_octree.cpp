@@ -327,7 +327,7 @@ void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, si
         below[r] = (uint32_t)std::min<uint64_t>(sum, 0xffffffffu);
     }
     out.nodes.assign(nodes, nodes + n_rec);
-    out.slots.assign(slots, slots + n_slots);
+    for (NodeRec& r : out.nodes) r.pad[0] = r.pad[1] = r.pad[2] = 0;  // a record that owns no cluster: an empty list
     out.root_info1 = root_info[1];
     std::vector<uint32_t> roots;
     if (below[root_info[0]] <= kClusterMaxLeaves) {
@@ -347,34 +347,50 @@ void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, si
     bool any_repeat = false;
     std::vector<uint32_t> stack;
     std::vector<std::pair<uint32_t, uint32_t>> leaves;  // (first slot, position of its info pair = record * 8 + octant)
-    std::vector<std::pair<uint32_t, uint32_t>> listed;  // (triangle, ordinal)
-    // numbers the leaves of one cluster in slot order (= breadth-first leaf order) and gives every slot its triangle's leaf set
-    auto annotate = [&]() {
+    std::vector<std::pair<uint32_t, uint32_t>> listed;  // (triangle, slot)
+    // One cluster: numbers its leaves in slot order (= breadth-first leaf order), appends its distinct triangles in
+    // ascending index, each with its leaf set, padded to whole blocks of 4 with records that no leaf lists, and writes
+    // where that list is into the padding words of record `owner`.
+    auto finish_cluster = [&](uint32_t owner) {
         std::sort(leaves.begin(), leaves.end());
         listed.clear();
         for (size_t k = 0; k < leaves.size(); ++k) {
             const uint32_t r = leaves[k].second >> 3, o = leaves[k].second & 7u;
             out.nodes[r].info[o][0] = leaves[k].first | ((uint32_t)k << kClusterOrdShift);
-            for (uint32_t j = 0; j < nodes[r].info[o][1]; ++j) listed.emplace_back(slots[leaves[k].first + j].tri, (uint32_t)k);
+            for (uint32_t j = 0; j < nodes[r].info[o][1]; ++j)
+                listed.emplace_back(slots[leaves[k].first + j].tri, leaves[k].first + j);
         }
+        // the ordinal of a slot's leaf: the last leaf whose first slot is <= the slot
+        auto leaf_of = [&](uint32_t slot) {
+            size_t lo = 0, hi = leaves.size();
+            while (hi - lo > 1) {
+                const size_t mid = (lo + hi) / 2;
+                if (leaves[mid].first <= slot) lo = mid;
+                else hi = mid;
+            }
+            return (uint32_t)lo;
+        };
         std::sort(listed.begin(), listed.end());
+        const size_t first = out.tris.size();
         size_t a = 0;
         while (a < listed.size()) {
             size_t b = a;
             uint32_t set = 0;
-            while (b < listed.size() && listed[b].first == listed[a].first) set |= 1u << listed[b++].second;
+            while (b < listed.size() && listed[b].first == listed[a].first) set |= 1u << leaf_of(listed[b++].second);
             any_repeat = any_repeat || b - a > 1;
-            for (size_t k = a; k < b; ++k) {
-                const uint32_t leaf = listed[k].second;
-                const uint32_t r = leaves[leaf].second >> 3, o = leaves[leaf].second & 7u;
-                const uint32_t begin = leaves[leaf].first, count = nodes[r].info[o][1];
-                // leaf lists are ascending in triangle index
-                const LeafTri* lo = std::lower_bound(slots + begin, slots + begin + count, listed[a].first,
-                                                     [](const LeafTri& s, uint32_t tri) { return s.tri < tri; });
-                out.slots[(size_t)(lo - slots)].pad0 = set;
-            }
+            LeafTri t = slots[listed[a].second];
+            t.pad0 = set;
+            t.pad1 = 0;
+            out.tris.push_back(t);
             a = b;
         }
+        while ((out.tris.size() - first) % 4 != 0) {
+            LeafTri t;
+            std::memset(&t, 0, sizeof t);
+            out.tris.push_back(t);
+        }
+        out.nodes[owner].pad[0] = (uint32_t)first;
+        out.nodes[owner].pad[1] = (uint32_t)(out.tris.size() - first);
     };
     for (const uint32_t root : roots) {  // a subtree
         leaves.clear();
@@ -389,7 +405,7 @@ void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, si
                 else leaves.emplace_back(i0, r * 8u + (uint32_t)o);
             }
         }
-        annotate();
+        finish_cluster(root);
     }
     for (size_t r = 0; r < n_rec; ++r) {  // the leaf children of a node above the subtrees
         if (below[r] <= kClusterMaxLeaves) continue;
@@ -398,7 +414,7 @@ void cluster_octree(const NodeRec* nodes, size_t n_rec, const LeafTri* slots, si
             const uint32_t i0 = nodes[r].info[o][0], i1 = nodes[r].info[o][1];
             if (i1 != 0 && !(i1 & kChildInternal)) leaves.emplace_back(i0, (uint32_t)r * 8u + (uint32_t)o);
         }
-        if (!leaves.empty()) annotate();
+        if (!leaves.empty()) finish_cluster((uint32_t)r);
     }
     out.n_clusters = any_repeat ? (uint32_t)std::max<size_t>(roots.size(), 1) : 0u;
     if (out.n_clusters == 0) out = ClusterForm();

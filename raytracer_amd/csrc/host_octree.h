@@ -90,17 +90,20 @@ struct FlatOctree {
 // Clustered form of a tree that is too big for the small-tree form.  The leaves are grouped into CLUSTERS: the leaves
 // of each maximal subtree with at most kClusterMaxLeaves leaves, and -- above those subtrees -- the leaf children of
 // each node.  For a cluster the wave-together any-hit walk first only records, per lane, which of the cluster's leaves
-// the lane reaches (one bit per leaf ordinal; ordinals follow the slot order) and then tests every triangle listed by
-// the reached leaves ONCE, for all lanes whose reached leaves list it -- instead of once per listing leaf (a wall
-// triangle of a Cornell box is listed by most of the root's octants).  nodes = the tree's records with
-// (a) kChildCluster set in info[1] of every internal child that is the root of such a subtree and (b) info[0] of every
-// leaf = slot index | ordinal << kClusterOrdShift; slots = the leaf slots with pad0 = the set of the cluster's leaves
-// (by ordinal) that list the slot's triangle.
+// the lane reaches (one bit per leaf ordinal; ordinals follow the slot order) and then walks the cluster's list of
+// DISTINCT triangles once: a triangle is tested for all lanes whose reached leaves list it -- instead of once per
+// listing leaf (a wall triangle of a Cornell box is listed by most of the root's octants).
+//   nodes = the tree's records with (a) kChildCluster set in info[1] of every internal child that is the root of such
+//           a subtree, (b) info[0] of every leaf = slot index | ordinal << kClusterOrdShift, and (c) in the record that
+//           owns a cluster (the subtree's root, or the node whose leaf children form it) pad[0] = index of the
+//           cluster's first record in `tris`, pad[1] = number of its records (a multiple of 4);
+//   tris  = per cluster its distinct triangles in ascending index, pad0 = the set of the cluster's leaves (by ordinal)
+//           that list the triangle; lists are padded to whole blocks of 4 with all-zero records (listed by no leaf).
 struct ClusterForm {
     std::vector<NodeRec> nodes;
-    std::vector<LeafTri> slots;
+    std::vector<LeafTri> tris;
     uint32_t root_info1 = 0;  // root_info[1], with kChildCluster if the whole tree is one cluster
-    uint32_t n_clusters = 0;
+    uint32_t n_clusters = 0;  // subtree clusters (at least 1 when the form applies)
 };
 // Fills `out` from the flattened tree; leaves it empty (n_clusters = 0) when the form does not apply: root leaf, no
 // cluster with a triangle listed twice, or slot indices that need more than kClusterOrdShift bits.

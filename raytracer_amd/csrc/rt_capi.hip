@@ -203,7 +203,7 @@ struct rt_ads {
     DevBuf<NodeRec> d_flat_nodes;
     // clustered form (ClusterForm in host_octree.h): any-hit walks of trees that stay in the wave-together form
     DevBuf<NodeRec> d_cl_nodes;
-    DevBuf<LeafTri> d_cl_slots;
+    DevBuf<LeafTri> d_cl_tris;
     uint32_t n_clusters = 0, cl_root_info1 = 0;
     bool use_clusters = true;
     DevBuf<TriShade> d_tri_shade;
@@ -245,7 +245,7 @@ DevOctree dev_tree(const rt_ads* a) {
     t.n_flat_tris = a->use_flat ? (uint32_t)a->n_flat_tris : 0u;
     const bool clustered = a->use_clusters && a->n_clusters != 0;
     t.cl_nodes = clustered ? a->d_cl_nodes.p : nullptr;
-    t.cl_slots = clustered ? a->d_cl_slots.p : nullptr;
+    t.cl_tris = clustered ? a->d_cl_tris.p : nullptr;
     t.cl_root_info1 = a->cl_root_info1;
     return t;
 }
@@ -472,15 +472,17 @@ int rt_host_tree_export_flat(const rt_host_tree* t, void* node_records, void* le
     }
     return RT_OK;
 }
-int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* leaf_slots, uint32_t* root_info1, uint32_t* n_clusters) {
+int rt_host_tree_export_clustered(const rt_host_tree* t, void* node_records, void* cluster_triangles, uint64_t* n_cluster_triangles,
+                                  uint32_t* root_info1, uint32_t* n_clusters) {
     if (!t) return fail(RT_ERR_INVALID, "null argument");
     ClusterForm cf;
     if (!t->host.empty) cluster_octree(t->flat.nodes.data(), t->flat.nodes.size(), t->flat.slots.data(), t->flat.slots.size(), t->flat.root_info, cf);
     if (n_clusters) *n_clusters = cf.n_clusters;
     if (root_info1) *root_info1 = cf.root_info1;
+    if (n_cluster_triangles) *n_cluster_triangles = cf.tris.size();
     if (cf.n_clusters == 0) return RT_OK;
     if (node_records) memcpy(node_records, cf.nodes.data(), cf.nodes.size() * sizeof(NodeRec));
-    if (leaf_slots) memcpy(leaf_slots, cf.slots.data(), cf.slots.size() * sizeof(LeafTri));
+    if (cluster_triangles) memcpy(cluster_triangles, cf.tris.data(), cf.tris.size() * sizeof(LeafTri));
     return RT_OK;
 }
 int rt_host_tree_stats(const rt_host_tree* t, rt_tree_stats* out) {
@@ -529,7 +531,7 @@ void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
     a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
-    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_slots.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
+    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
     for (auto& l : a->levels) l.release();
     a->search.release();
     a->d_qstats.release();
@@ -619,10 +621,9 @@ int make_cluster_form(rt_ads* a) {
     cluster_octree(nodes.data(), nodes.size(), slots.data(), slots.size(), a->root_info, cf);
     if (cf.n_clusters == 0) return RT_OK;
     HIP_TRY(a->d_cl_nodes.reserve(cf.nodes.size()));
-    HIP_TRY(a->d_cl_slots.reserve(cf.slots.size() + 4));  // +4: triangle records are fetched in groups of 4
+    HIP_TRY(a->d_cl_tris.reserve(cf.tris.size()));  // (every list is a whole number of 4-record blocks)
     HIP_TRY(hipMemcpy(a->d_cl_nodes.p, cf.nodes.data(), cf.nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(a->d_cl_slots.p, cf.slots.data(), cf.slots.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(a->d_cl_slots.p + cf.slots.size(), 0, 4 * sizeof(LeafTri)));
+    HIP_TRY(hipMemcpy(a->d_cl_tris.p, cf.tris.data(), cf.tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
     a->n_clusters = cf.n_clusters;
     a->cl_root_info1 = cf.root_info1;
     return RT_OK;

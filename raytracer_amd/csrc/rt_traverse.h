@@ -45,7 +45,7 @@ struct DevOctree {
     uint32_t n_flat_tris;
     // Clustered form (cl_nodes != nullptr; any-hit walks of mid-size trees): see ClusterForm in host_octree.h.
     const NodeRec* cl_nodes;
-    const LeafTri* cl_slots;
+    const LeafTri* cl_tris;
     uint32_t cl_root_info1;
 };
 
@@ -117,8 +117,8 @@ __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, floa
 
 #ifdef RT_LANE_PROFILE
 // Any-hit walks of the wave-together forms.  Plain walk: 0 waves, 1 node visits, 2 leaf visits, 3 triangle tests started.
-// Clustered walk: 8 waves, 9 node visits, 10 cluster visits, 11 leaves reached, 12 slots scanned, 13 of them skipped
-// (tested at an earlier leaf), 14 of them needed by no lane, 15 triangle tests started, 7 tests of leaves outside clusters.
+// Clustered walk: 8 waves, 9 node visits, 10 subtree clusters entered, 11 leaves reached, 12 list records scanned, 13 of
+// them listed by no reached leaf, 14 of them needed by no live lane, 15 triangle tests started.
 __device__ unsigned long long g_wave_prof[16];
 #define RT_WPROF(k, v) do { if (__lane_id() == 0) atomicAdd(&g_wave_prof[k], (unsigned long long)(v)); } while (0)
 #else
@@ -356,16 +356,14 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     if (FLAT) flat_tests<ANY, CULL>(T, all, reach, o, d, t_limit, h);
 }
 
-// One slot of a reached leaf in the test phase of a cluster (record jj of the 4-record block).  lm = the cluster's
-// leaves that list the slot's triangle; `earlier` = the leaves the wave reached before this one: a triangle that one of
-// them lists has been tested there, for every lane that needs it.
+// One record of a cluster's triangle list (record jj of the 4-record block).  lm = the cluster's leaves that list the
+// triangle, wreach = the leaves some lane of the wave reaches, reach = the leaves this lane reaches.
 template <bool CULL>
-__device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, bool in_leaf, uint32_t earlier, lanemask alive, uint32_t reach,
-                                            f3 o, f3 d, float t_limit, HitState& h) {
+__device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, uint32_t wreach, lanemask alive, uint32_t reach, f3 o, f3 d,
+                                            float t_limit, HitState& h) {
     const uint32_t lm = RT_W(blk, 12 * jj + 10);
-    if (!in_leaf) return;
     RT_WPROF(12, 1);
-    if ((lm & earlier) != 0) {
+    if ((lm & wreach) == 0) {
         RT_WPROF(13, 1);
         return;
     }
@@ -385,37 +383,38 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, bo
 }
 
 // Any-hit walk over the clustered form.  Leaves are never pushed: the lanes that reach leaf k of the current cluster
-// set bit k of `reach`, the wave sets bit k of `wreach` and keeps the leaf's (first slot, count) in lane k of two
-// registers.  A cluster made of a node's leaf children is complete after that node's visit; a subtree cluster once the
-// stack is back at its height of the moment its root was visited.  Then the reached leaves are scanned in slot order and
-// each triangle is tested once, at the first reached leaf that lists it, for all lanes that reach any leaf listing it.
-// The candidate set of every ray is the one of the plain walk -- only the number of times the wave tests a triangle
-// changes -- so the answers are the same.
+// set bit k of `reach` and the wave sets bit k of `wreach`.  A cluster made of a node's leaf children is complete after
+// that node's visit; a subtree cluster once the stack is back at its height of the moment its root was visited.  Then
+// the cluster's list of distinct triangles is walked once: a triangle that a reached leaf lists is tested for all lanes
+// that reach any leaf listing it.  The candidate set of every ray is the one of the plain walk -- only the number of
+// times the wave tests a triangle changes -- so the answers are the same.
 template <bool CULL>
 __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
     WaveStack st;
     cu32_p nodes = as_const_u(T.cl_nodes);
-    cu32_p slots = as_const_u(T.cl_slots);
+    cu32_p tris = as_const_u(T.cl_tris);
     uint32_t i0 = T.root_info0, i1 = T.cl_root_info1;
     lanemask mine = all;
     int cl_base = -1;  // stack height at the visit of a subtree cluster's root; -1 outside those
     uint32_t reach = 0, wreach = 0;
-    int leaf_begin = 0, leaf_count = 0;  // lane k: leaf k of the cluster
+    uint32_t list_begin = 0, list_count = 0;  // the current cluster's records in T.cl_tris
     RT_WPROF(8, 1);
     for (;;) {  // (i0, i1) is an internal node: only those are pushed
         RT_WPROF(9, 1);
-        if (cl_base < 0) {
+        cu32_p rec = nodes + (size_t)i0 * 32;
+        const u32x16 pl = sload16(rec);
+        const u32x16 info = sload16(rec + 16);
+        if (cl_base < 0) {  // this node owns the cluster that its leaf children (or, a subtree root, all leaves below it) belong to
             reach = 0;
             wreach = 0;
+            list_begin = pl[13];
+            list_count = pl[14];
             if (i1 & kChildCluster) {
                 RT_WPROF(10, 1);
                 cl_base = st.sp;
             }
         }
-        cu32_p rec = nodes + (size_t)i0 * 32;
-        const u32x16 pl = sload16(rec);
-        const u32x16 info = sload16(rec + 16);
         SlabSides sl;
         slab_sides(pl, o, inv, sl);
 #pragma unroll
@@ -427,12 +426,10 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
             if (c1 & kChildInternal) {
                 st.push(info[2 * c], c1, pm);
             } else {
-                const uint32_t ord = info[2 * c] >> kClusterOrdShift, bit = 1u << ord;
+                const uint32_t bit = 1u << (info[2 * c] >> kClusterOrdShift);
                 reach |= lane_of(pm) ? bit : 0u;
                 wreach |= bit;
                 RT_WPROF(11, 1);
-                leaf_begin = write_lane((int)(info[2 * c] & kClusterSlotMask), (int)ord, leaf_begin);
-                leaf_count = write_lane((int)c1, (int)ord, leaf_count);
             }
         }
         // next node that still has a live lane; a cluster whose walk is complete is tested first
@@ -440,22 +437,15 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
         for (;;) {
             if (cl_base < 0 || st.sp == cl_base) {
                 cl_base = -1;
-                uint32_t w = wreach;
-                wreach = 0;
-                const uint32_t reached = w;
-                while (w != 0 && (all & ~h.found) != 0) {
-                    const uint32_t k = (uint32_t)__builtin_ctz(w);
-                    const uint32_t earlier = reached & ((1u << k) - 1u);
-                    w &= w - 1u;
-                    const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane(leaf_begin, (int)k);
-                    const uint32_t count = (uint32_t)__builtin_amdgcn_readlane(leaf_count, (int)k);
-                    for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
-                        const Block48 blk = sload48(slots + (size_t)(begin + k0) * 12);
-                        cluster_one<CULL>(blk, 0, true, earlier, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 1, k0 + 1 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 2, k0 + 2 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 3, k0 + 3 < count, earlier, all & ~h.found, reach, o, d, t_limit, h);
+                if (wreach != 0) {
+                    for (uint32_t k0 = 0; k0 < list_count && (all & ~h.found) != 0; k0 += kTriChunk) {
+                        const Block48 blk = sload48(tris + (size_t)(list_begin + k0) * 12);
+                        cluster_one<CULL>(blk, 0, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 1, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 2, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL>(blk, 3, wreach, all & ~h.found, reach, o, d, t_limit, h);
                     }
+                    wreach = 0;
                 }
             }
             if (st.sp == 0) break;

@@ -75,8 +75,8 @@ def test_flat_layout(scenes, scene, mb, md):
 @pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3), ("sphere", 2, 12), ("original", 1, 6)])
 def test_clustered_layout(scenes, scene, mb, md):
     """The clustered form is a re-labelling of the flat layout: same planes and links, every leaf in exactly one cluster
-    (a subtree of <= 32 leaves, or the leaf children of a node above those) with ordinals in slot order, and every
-    slot's mask = the leaves of its cluster that list its triangle."""
+    (a subtree of <= 32 leaves, or the leaf children of a node above those) with ordinals in slot order, and per cluster
+    a list of its distinct triangles, each with the set of the cluster's leaves that list it."""
     sc = scenes[scene]
     ht = HostTree(sc.pos, mb, md)
     recs, slots, root = ht.export_flat()
@@ -89,19 +89,13 @@ def test_clustered_layout(scenes, scene, mb, md):
             i0, i1 = int(recs[r]["info"][o, 0]), int(recs[r]["info"][o, 1])
             if i1:
                 below[r] += below[i0] if i1 & INTERNAL else 1
-    if cl is None:
-        # allowed only when no cluster lists a triangle twice; with these scenes every tree has such a cluster
-        assert n == 0
-        return
-    crecs, cslots, croot1, n_sub = cl
+    assert cl is not None  # every one of these trees has a cluster that lists a triangle twice
+    crecs, ctris, croot1, n_sub = cl
     assert same_bits(crecs["lo"], recs["lo"]) and same_bits(crecs["hi"], recs["hi"]) and same_bits(crecs["nonempty"], recs["nonempty"])
-    for k in ("a", "e1", "e2", "tri"):
-        assert same_bits(cslots[k], slots[k])
     assert (croot1 & ~CLUSTER) == int(root[1]) and bool(croot1 & CLUSTER) == (below[0] <= 32)
-    # clusters: key -> list of (first slot, count, ordinal)
-    clusters = {}
+    clusters = {}  # owner record -> list of (first slot, count, ordinal)
 
-    def walk(r, key):
+    def walk(r, owner):
         for o in range(8):
             i0, i1 = int(recs[r]["info"][o, 0]), int(recs[r]["info"][o, 1])
             c0, c1 = int(crecs[r]["info"][o, 0]), int(crecs[r]["info"][o, 1])
@@ -109,32 +103,43 @@ def test_clustered_layout(scenes, scene, mb, md):
                 assert c1 == 0
             elif i1 & INTERNAL:
                 assert c0 == i0 and (c1 & ~CLUSTER) == i1
-                is_root = key is None and below[i0] <= 32
+                is_root = owner is None and below[i0] <= 32
                 assert bool(c1 & CLUSTER) == is_root
-                walk(i0, ("sub", i0) if is_root else key)
+                walk(i0, i0 if is_root else owner)
             else:
                 assert c1 == i1 and (c0 & 0xffffff) == i0
-                clusters.setdefault(key if key is not None else ("own", r), []).append((i0, i1, c0 >> 24))
+                clusters.setdefault(owner if owner is not None else r, []).append((i0, i1, c0 >> 24))
 
-    walk(0, ("sub", 0) if below[0] <= 32 else None)
-    assert sum(len(v) for v in clusters.values()) == int((recs["info"][:, :, 1] != 0).sum() - (recs["info"][:, :, 1] & INTERNAL != 0).sum())
-    assert len([k for k in clusters if k[0] == "sub"]) == n_sub
-    seen = np.zeros(len(slots), bool)
+    walk(0, 0 if below[0] <= 32 else None)
+    n_leaves = int((recs["info"][:, :, 1] != 0).sum() - (recs["info"][:, :, 1] & INTERNAL != 0).sum())
+    assert sum(len(v) for v in clusters.values()) == n_leaves
+    assert len([k for k in clusters if below[k] <= 32]) == n_sub
+    used = np.zeros(len(ctris), bool)
     repeats = 0
-    for key, leaves in clusters.items():
-        leaves.sort()
+    for r in range(n):
+        begin, count = int(crecs[r]["pad"][0]), int(crecs[r]["pad"][1])
+        assert int(crecs[r]["pad"][2]) == 0
+        if r not in clusters:
+            assert count == 0
+            continue
+        leaves = sorted(clusters[r])
         assert [l[2] for l in leaves] == list(range(len(leaves))) and len(leaves) <= 32  # ordinals follow the slot order
         listed = {}
         for b, c, k in leaves:
-            for t in slots["tri"][b:b + c]:
-                listed[int(t)] = listed.get(int(t), 0) | (1 << k)
-        for b, c, k in leaves:
             for j in range(b, b + c):
-                assert int(cslots["pad"][j, 0]) == listed[int(slots["tri"][j])] and int(cslots["pad"][j, 1]) == 0
-                assert not seen[j]
-                seen[j] = True
-        repeats += sum(1 for m in listed.values() if m & (m - 1))
-    assert seen.all() and repeats > 0
+                listed.setdefault(int(slots["tri"][j]), [0, j])[0] |= 1 << k
+        tris = sorted(listed)
+        assert count % 4 == 0 and 0 <= count - len(tris) < 4 and not used[begin:begin + count].any()
+        used[begin:begin + count] = True
+        got = ctris[begin:begin + count]
+        assert np.array_equal(got["tri"][:len(tris)], np.array(tris, np.uint32))
+        assert [int(x) for x in got["pad"][:len(tris), 0]] == [listed[t][0] for t in tris]
+        src = slots[[listed[t][1] for t in tris]]
+        for k in ("a", "e1", "e2"):
+            assert same_bits(got[k][:len(tris)], src[k])
+        assert not np.ascontiguousarray(got[len(tris):]).view(np.uint8).any()  # padding: listed by no leaf
+        repeats += sum(1 for t in tris if listed[t][0] & (listed[t][0] - 1))
+    assert used.all() and repeats > 0
 
 
 def test_synthetic_tree_equals_oracle_and_reference(orc):

@@ -54,5 +54,4 @@ if w[0]:
     print(f"wave any-hit, plain walk: waves {w[0]}  per wave: node visits {w[1] / w[0]:.2f} leaf visits {w[2] / w[0]:.2f} triangle tests started {w[3] / w[0]:.2f}")
 if w[8]:
     print(f"wave any-hit, clustered walk: waves {w[8]}  per wave: node visits {w[9] / w[8]:.2f} cluster visits {w[10] / w[8]:.2f} leaves reached {w[11] / w[8]:.2f} "
-          f"slots scanned {w[12] / w[8]:.2f} (tested earlier {w[13] / w[8]:.2f}, needed by no lane {w[14] / w[8]:.2f}) triangle tests started {w[15] / w[8]:.2f} "
-          f"+ outside clusters {w[3] / w[8]:.2f}")
+          f"list records scanned {w[12] / w[8]:.2f} (listed by no reached leaf {w[13] / w[8]:.2f}, needed by no live lane {w[14] / w[8]:.2f}) triangle tests started {w[15] / w[8]:.2f}")
