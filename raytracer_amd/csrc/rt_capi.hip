@@ -134,7 +134,17 @@ constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots ar
     } while (0)
 
 template <class... Args>
-void launch_shadow(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+void launch_shadow(bool cull, int mode, bool fast_tri, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+    if (fast_tri && mode == MODE_CLUSTER) {
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_CLUSTER, 4, true>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_CLUSTER, 4, true>), grid, block, 0, stream, args...);
+        return;
+    }
+    if (fast_tri && mode == MODE_WAVE) {
+        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_WAVE, 4, true>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<false, MODE_WAVE, 4, true>), grid, block, 0, stream, args...);
+        return;
+    }
     if (mode == MODE_POOL) {  // one-wave blocks
         if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_POOL, 1>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_shadow<false, MODE_POOL, 1>), grid, block, 0, stream, args...);
@@ -206,6 +216,9 @@ struct rt_ads {
     DevBuf<LeafTri> d_cl_tris;
     uint32_t n_clusters = 0, cl_root_info1 = 0;
     bool use_clusters = true;
+    // every triangle has |e1| * |e2| far below the range limit of the refined reciprocal: shadow rays (unit directions)
+    // may use the any-hit triangle test that never needs the full division (any_hit_exec)
+    bool fast_tri = false;
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
     DevBuf<MatDev> d_mats;
@@ -843,6 +856,25 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
+    {
+        double m1 = 0.0, m2 = 0.0;
+        bool finite = true;
+        for (uint64_t i = 0; i < n; ++i) {
+            const float* p = positions + i * 9;
+            double a1 = 0.0, a2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double x1 = (double)p[3 + k] - (double)p[k], x2 = (double)p[6 + k] - (double)p[k];
+                a1 += x1 * x1;
+                a2 += x2 * x2;
+            }
+            finite = finite && std::isfinite(a1) && std::isfinite(a2);
+            m1 = std::max(m1, a1);
+            m2 = std::max(m2, a2);
+        }
+        // |d| = |dot(e1, cross(s, e2))| <= |e1| |e2| |s|; a factor 2^10 covers |s| = 1 + a few ulp and every rounding on the way
+        a->fast_tri = finite && std::sqrt(m1) * std::sqrt(m2) * 1024.0 < (double)kRcpFastMax;
+        if (const char* e = getenv("RT_DISABLE_FAST_TRI")) a->fast_tri = a->fast_tri && !(e[0] == '1');
+    }
     a->use_clusters = true;
     if (const char* e = getenv("RT_DISABLE_CLUSTERS")) a->use_clusters = !(e[0] == '1');
     if (int rc = make_cluster_form(a)) return rc;
@@ -1466,7 +1498,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 const dim3 block_a(wave_a ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
-                launch_shadow(F.cull != 0, mode_a, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
+                launch_shadow(F.cull != 0, mode_a, a->fast_tri, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
                            lv.work.p, lv.vis.p, words, pshift, gshift, cnt, sparse_a);
                 HIP_TRY(hipGetLastError());
                 st.launches_shadow++;

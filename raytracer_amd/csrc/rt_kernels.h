@@ -71,14 +71,15 @@ __device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool&
     ok = lane < (64u >> sparse);
     return ((g >> 6) << (6u - sparse)) + lane;
 }
-template <bool ANY, bool CULL, int MODE>
+// FAST: any-hit rays with unit-length directions in a scene within the bound of any_hit_exec (wave-together forms only).
+template <bool ANY, bool CULL, int MODE, bool FAST = false>
 __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_CLUSTER) {
         static_assert(ANY, "the clustered form serves any-hit queries");
-        traverse_any_clustered<CULL>(T, valid, o, d, t_limit, h);
-    } else traverse<ANY, CULL>(T, valid, o, d, t_limit, h);
+        traverse_any_clustered<CULL, FAST>(T, valid, o, d, t_limit, h);
+    } else traverse<ANY, CULL, FAST>(T, valid, o, d, t_limit, h);
 }
 
 struct alignas(16) TriShade {  // per triangle in Build order
@@ -458,7 +459,8 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // if not shadowed (hit j innermost); the bits of a word come from one ballot, so no two lanes write the same word.
 // WAVES: waves per block.  The kernel has no block-level step, so the per-lane and pool forms run one-wave blocks:
 // a wave that finishes frees its slot at once instead of waiting for the slowest of four.
-template <bool CULL, int MODE, int WAVES>
+// FAST: see trace<>.
+template <bool CULL, int MODE, int WAVES, bool FAST = false>
 __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
         HitState h;
-        trace<true, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], on, P, d_l, dist, h);
+        trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], on, P, d_l, dist, h);
         const lanemask unshadowed = on_mask & ~h.found;
         const uint32_t word = smp >> 5;
         if (lit && writer && word < words)

@@ -90,6 +90,110 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
     return ok;
 }
 
+// The any-hit form of the same test, written in ISA: found |= lanes of `need` whose ray hits the triangle at a usable
+// distance below t_limit (renderer.cc:298-302).  The compiled form above keeps every lane predicate in a scalar mask and
+// pays four or five scalar instructions per stage for it (and-not, compare with zero, branch, ...); on gfx950 a scalar
+// instruction costs a SIMD 1.7 times the issue time of a vector one (measured, tools/salu_rate.hip), and the wave-together
+// any-hit kernels were bound by exactly that.  Here the predicate IS the EXEC mask: v_cmpx narrows it stage by stage
+// for free and one s_cbranch_execz per stage leaves when no lane is left -- 8 scalar instructions per test instead of 22.
+// Same operations in the same order as ray_triangle<> (no fused multiply-add outside the reciprocal's refinement
+// chain, which is rcp_refined's), same comparisons (a NaN falls through the same way).
+// Only for callers that guarantee |d| <= kRcpFastMax for every lane that passes the first stage: unit-length (or zero,
+// or NaN) ray directions and a scene whose triangles have |e1| * |e2| below that bound -- then 1 / d never needs the
+// full division.  rec: a, e1, e2 in wave-uniform registers.
+template <bool CULL>
+__device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax, float ay, float az, float e1x, float e1y, float e1z,
+                                             float e2x, float e2y, float e2z, float t_limit, lanemask& found) {
+    float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
+    lanemask save;
+    const float eps = kEps;
+    const uint32_t dmask = CULL ? 0xffffffffu : 0x7fffffffu;  // the first stage compares d, or |d| when back faces count
+    asm volatile(
+        "s_mov_b64 %[save], exec\n"
+        "s_mov_b64 exec, %[need]\n"
+        // p = cross(s, e2)
+        "v_mul_f32 %[p0], %[e2z], %[sy]\n"
+        "v_mul_f32 %[t0], %[e2y], %[sz]\n"
+        "v_sub_f32 %[p0], %[p0], %[t0]\n"
+        "v_mul_f32 %[p1], %[e2x], %[sz]\n"
+        "v_mul_f32 %[t0], %[e2z], %[sx]\n"
+        "v_sub_f32 %[p1], %[p1], %[t0]\n"
+        "v_mul_f32 %[p2], %[e2y], %[sx]\n"
+        "v_mul_f32 %[t0], %[e2x], %[sy]\n"
+        "v_sub_f32 %[p2], %[p2], %[t0]\n"
+        // d = dot(e1, p)
+        "v_mul_f32 %[d], %[e1x], %[p0]\n"
+        "v_mul_f32 %[t0], %[e1y], %[p1]\n"
+        "v_add_f32 %[d], %[d], %[t0]\n"
+        "v_mul_f32 %[t0], %[e1z], %[p2]\n"
+        "v_add_f32 %[d], %[t0], %[d]\n"
+        // collision_detection.h:28-35: leave unless !(d < eps) / !(|d| < eps)
+        "v_and_b32 %[t0], %[dmask], %[d]\n"
+        "v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n"
+        "s_cbranch_execz 1f\n"
+        // 1 / d (rcp_refined), q = o - a in the shadow of the reciprocal
+        "v_rcp_f32 %[r], %[d]\n"
+        "v_subrev_f32 %[q0], %[ax], %[ox]\n"
+        "v_subrev_f32 %[q1], %[ay], %[oy]\n"
+        "v_subrev_f32 %[q2], %[az], %[oz]\n"
+        "v_fma_f32 %[e], -%[d], %[r], 1.0\n"
+        "v_fmac_f32 %[r], %[e], %[r]\n"
+        "v_fma_f32 %[e], -%[d], %[r], 1.0\n"
+        "v_fma_f32 %[e], %[e], %[r], %[r]\n"
+        "v_fma_f32 %[d], -%[d], %[e], 1.0\n"
+        "v_fmac_f32 %[e], %[d], %[r]\n"
+        // u = d_inv * dot(q, p); leave unless !(u < 0) && !(u > 1)
+        "v_mul_f32 %[u], %[q0], %[p0]\n"
+        "v_mul_f32 %[t0], %[q1], %[p1]\n"
+        "v_add_f32 %[u], %[u], %[t0]\n"
+        "v_mul_f32 %[t0], %[q2], %[p2]\n"
+        "v_add_f32 %[u], %[t0], %[u]\n"
+        "v_mul_f32 %[u], %[u], %[e]\n"
+        "v_cmpx_ngt_f32 vcc, 0, %[u]\n"
+        "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n"
+        "s_cbranch_execz 1f\n"
+        // w = cross(q, e1)
+        "v_mul_f32 %[p0], %[e1z], %[q1]\n"
+        "v_mul_f32 %[t0], %[e1y], %[q2]\n"
+        "v_sub_f32 %[p0], %[p0], %[t0]\n"
+        "v_mul_f32 %[p1], %[e1x], %[q2]\n"
+        "v_mul_f32 %[t0], %[e1z], %[q0]\n"
+        "v_sub_f32 %[p1], %[p1], %[t0]\n"
+        "v_mul_f32 %[p2], %[e1y], %[q0]\n"
+        "v_mul_f32 %[t0], %[e1x], %[q1]\n"
+        "v_sub_f32 %[p2], %[p2], %[t0]\n"
+        // v = d_inv * dot(w, s); leave unless !(v < 0) && !(u + v > 1)
+        "v_mul_f32 %[d], %[p0], %[sx]\n"
+        "v_mul_f32 %[t0], %[p1], %[sy]\n"
+        "v_add_f32 %[d], %[d], %[t0]\n"
+        "v_mul_f32 %[t0], %[p2], %[sz]\n"
+        "v_add_f32 %[d], %[t0], %[d]\n"
+        "v_mul_f32 %[d], %[d], %[e]\n"
+        "v_add_f32 %[u], %[u], %[d]\n"
+        "v_cmpx_ngt_f32 vcc, 0, %[d]\n"
+        "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n"
+        "s_cbranch_execz 1f\n"
+        // t = d_inv * dot(e2, w); an occluder unless t == inf or t < eps (renderer.cc:298), and only below the limit (:302)
+        "v_mul_f32 %[d], %[e2x], %[p0]\n"
+        "v_mul_f32 %[t0], %[e2y], %[p1]\n"
+        "v_add_f32 %[d], %[d], %[t0]\n"
+        "v_mul_f32 %[t0], %[e2z], %[p2]\n"
+        "v_add_f32 %[d], %[t0], %[d]\n"
+        "v_mul_f32 %[d], %[d], %[e]\n"
+        "v_cmpx_neq_f32 vcc, 0x7f800000, %[d]\n"
+        "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n"
+        "v_cmpx_lt_f32 vcc, %[d], %[tl]\n"
+        "s_or_b64 %[found], %[found], exec\n"
+        "1:\n"
+        "s_mov_b64 exec, %[save]\n"
+        : [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [d] "=&v"(d), [r] "=&v"(r), [e] "=&v"(e), [q0] "=&v"(q0), [q1] "=&v"(q1),
+          [q2] "=&v"(q2), [u] "=&v"(u), [t0] "=&v"(t0), [save] "=&s"(save), [found] "+s"(found)
+        : [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] "s"(ax),
+          [ay] "s"(ay), [az] "s"(az), [e1x] "s"(e1x), [e1y] "s"(e1y), [e1z] "s"(e1z), [e2x] "s"(e2x), [e2y] "s"(e2y), [e2z] "s"(e2z),
+          [tl] "v"(t_limit), [eps] "s"(eps), [dmask] "s"(dmask)
+        : "vcc", "scc");
+}
+
 // Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the
 // reference recomputes the same three quotients for every box).
 __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
@@ -154,11 +258,17 @@ __device__ __forceinline__ Block48 sload48(cu32_p p) {
 constexpr int kTriChunk = 4;  // triangle records per scalar-load group (arrays are padded by this many records)
 
 // One record of a leaf's 4-record block (record j, global slot `slot`) for the lanes in `mine`.
-template <bool ANY, bool CULL>
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32_t slot, lanemask mine, f3 o, f3 d, float t_limit,
                                          HitState& h) {
     if (mine == 0) return;
     if (ANY) RT_WPROF(3, 1);
+    if constexpr (ANY && FAST) {
+        any_hit_exec<CULL>(mine, o, d, RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2), RT_F(blk, 12 * j + 3),
+                           RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5), RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8),
+                           t_limit, h.found);
+        return;
+    }
     const f3 a = mk(RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2));
     const f3 e1 = mk(RT_F(blk, 12 * j + 3), RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5));
     const f3 e2 = mk(RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8));
@@ -181,17 +291,17 @@ __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32
 
 // Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.  Records are read four at a time;
 // those past the leaf's end (the next leaf's, or the array's padding) get an empty lane mask.
-template <bool ANY, bool CULL>
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, lanemask mine, f3 o, f3 d, float t_limit,
                                            HitState& h) {
     cu32_p base = as_const_u(T.slots);
     for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)(begin + k0) * 12);
         const lanemask none = 0;
-        leaf_one<ANY, CULL>(blk, 0, begin + k0 + 0, ANY ? (mine & ~h.found) : mine, o, d, t_limit, h);
-        leaf_one<ANY, CULL>(blk, 1, begin + k0 + 1, k0 + 1 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
-        leaf_one<ANY, CULL>(blk, 2, begin + k0 + 2, k0 + 2 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
-        leaf_one<ANY, CULL>(blk, 3, begin + k0 + 3, k0 + 3 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST>(blk, 0, begin + k0 + 0, ANY ? (mine & ~h.found) : mine, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST>(blk, 1, begin + k0 + 1, k0 + 1 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST>(blk, 2, begin + k0 + 2, k0 + 2 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST>(blk, 3, begin + k0 + 3, k0 + 3 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
         if (ANY && (mine & ~h.found) == 0) return;  // every ray that reached this leaf is decided
     }
 }
@@ -204,12 +314,18 @@ __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, u
 // smaller ordinal of the first reached leaf that lists the triangle, then smaller triangle index (leaf lists are
 // ascending); the loop runs in ascending j, so an equal-t later triangle wins only with a smaller first leaf.
 // One triangle record of the small-tree pass (record jj of the 4-record block, triangle index j).
-template <bool ANY, bool CULL>
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint32_t j, lanemask alive, uint32_t reach, f3 o, f3 d,
                                          float t_limit, HitState& h) {
     const uint32_t lm = RT_W(blk, 12 * jj + 10);
     const lanemask need = alive & ballot64((reach & lm) != 0);
     if (need == 0) return;
+    if constexpr (ANY && FAST) {
+        any_hit_exec<CULL>(need, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
+                           RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8),
+                           t_limit, h.found);
+        return;
+    }
     const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
     const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
     const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
@@ -229,17 +345,17 @@ __device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint3
     }
 }
 
-template <bool ANY, bool CULL>
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
     cu32_p base = as_const_u(T.flat_tris);
     const uint32_t n = T.n_flat_tris;
     // The array is padded to whole blocks with records whose leaf mask is 0: no lane ever needs them.
     for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)j0 * 12);
-        flat_one<ANY, CULL>(blk, 0, j0 + 0, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL>(blk, 1, j0 + 1, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL>(blk, 2, j0 + 2, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL>(blk, 3, j0 + 3, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 0, j0 + 0, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 1, j0 + 1, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 2, j0 + 2, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 3, j0 + 3, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
         if (ANY && (all & ~h.found) == 0) return;  // every ray of the wave is decided
     }
 }
@@ -310,7 +426,7 @@ __device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c) {
 }
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
-template <bool ANY, bool CULL, bool FLAT>
+template <bool ANY, bool CULL, bool FLAT, bool FAST = false>
 __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
     WaveStack st;
@@ -339,7 +455,7 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
             }
         } else {
             if (ANY && !FLAT) RT_WPROF(2, 1);
-            leaf_tests<ANY, CULL>(T, i0, i1, mine, o, d, t_limit, h);
+            leaf_tests<ANY, CULL, FAST>(T, i0, i1, mine, o, d, t_limit, h);
         }
         // next entry that still has a live lane
         bool got = false;
@@ -353,12 +469,12 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
         }
         if (!got) break;
     }
-    if (FLAT) flat_tests<ANY, CULL>(T, all, reach, o, d, t_limit, h);
+    if (FLAT) flat_tests<ANY, CULL, FAST>(T, all, reach, o, d, t_limit, h);
 }
 
 // One record of a cluster's triangle list (record jj of the 4-record block).  lm = the cluster's leaves that list the
 // triangle, wreach = the leaves some lane of the wave reaches, reach = the leaves this lane reaches.
-template <bool CULL>
+template <bool CULL, bool FAST = false>
 __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, uint32_t wreach, lanemask alive, uint32_t reach, f3 o, f3 d,
                                             float t_limit, HitState& h) {
     const uint32_t lm = RT_W(blk, 12 * jj + 10);
@@ -373,6 +489,12 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, ui
         return;
     }
     RT_WPROF(15, 1);
+    if constexpr (FAST) {
+        any_hit_exec<CULL>(need, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
+                           RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8),
+                           t_limit, h.found);
+        return;
+    }
     const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
     const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
     const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
@@ -388,7 +510,7 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, ui
 // the cluster's list of distinct triangles is walked once: a triangle that a reached leaf lists is tested for all lanes
 // that reach any leaf listing it.  The candidate set of every ray is the one of the plain walk -- only the number of
 // times the wave tests a triangle changes -- so the answers are the same.
-template <bool CULL>
+template <bool CULL, bool FAST = false>
 __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
     WaveStack st;
@@ -440,10 +562,10 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
                 if (wreach != 0) {
                     for (uint32_t k0 = 0; k0 < list_count && (all & ~h.found) != 0; k0 += kTriChunk) {
                         const Block48 blk = sload48(tris + (size_t)(list_begin + k0) * 12);
-                        cluster_one<CULL>(blk, 0, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 1, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 2, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL>(blk, 3, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 0, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 1, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 2, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 3, wreach, all & ~h.found, reach, o, d, t_limit, h);
                     }
                     wreach = 0;
                 }
@@ -460,7 +582,8 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
     }
 }
 
-template <bool ANY, bool CULL>
+// FAST (any-hit only): the caller guarantees unit-length directions and a scene within the bound of any_hit_exec.
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
@@ -470,12 +593,12 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
     // A root that is a leaf makes every triangle a candidate without any box test (octree.cc:56-63,186-191);
     // traverse_impl handles it as a leaf entry.
-    if (T.n_flat_tris) traverse_impl<ANY, CULL, true>(T, all, o, d, t_limit, h);
-    else traverse_impl<ANY, CULL, false>(T, all, o, d, t_limit, h);
+    if (T.n_flat_tris) traverse_impl<ANY, CULL, true, FAST>(T, all, o, d, t_limit, h);
+    else traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, h);
 }
 
 // Any-hit query over the clustered form (T.cl_nodes must be set; the host launches this only for such trees).
-template <bool CULL>
+template <bool CULL, bool FAST = false>
 __device__ __forceinline__ void traverse_any_clustered(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
@@ -483,7 +606,7 @@ __device__ __forceinline__ void traverse_any_clustered(const DevOctree& T, bool 
     h.found = 0;
     const lanemask all = ballot64(valid);
     if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
-    traverse_clustered<CULL>(T, all, o, d, t_limit, h);
+    traverse_clustered<CULL, FAST>(T, all, o, d, t_limit, h);
 }
 
 }  // namespace rt
