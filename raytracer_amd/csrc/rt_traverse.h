@@ -101,97 +101,123 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 // Only for callers that guarantee |d| <= kRcpFastMax for every lane that passes the first stage: unit-length (or zero,
 // or NaN) ray directions and a scene whose triangles have |e1| * |e2| below that bound -- then 1 / d never needs the
 // full division.  rec: a, e1, e2 in wave-uniform registers.
-template <bool CULL>
+// The stages of the test, entered with EXEC = the lanes to test; leaves through label 1 with EXEC = the lanes that found
+// an occluder already or-ed into %[found].
+#define RT_ANY_HIT_STAGES \
+    /* p = cross(s, e2) */ \
+    "v_mul_f32 %[p0], %[e2z], %[sy]\n" \
+    "v_mul_f32 %[t0], %[e2y], %[sz]\n" \
+    "v_sub_f32 %[p0], %[p0], %[t0]\n" \
+    "v_mul_f32 %[p1], %[e2x], %[sz]\n" \
+    "v_mul_f32 %[t0], %[e2z], %[sx]\n" \
+    "v_sub_f32 %[p1], %[p1], %[t0]\n" \
+    "v_mul_f32 %[p2], %[e2y], %[sx]\n" \
+    "v_mul_f32 %[t0], %[e2x], %[sy]\n" \
+    "v_sub_f32 %[p2], %[p2], %[t0]\n" \
+    /* d = dot(e1, p) */ \
+    "v_mul_f32 %[d], %[e1x], %[p0]\n" \
+    "v_mul_f32 %[t0], %[e1y], %[p1]\n" \
+    "v_add_f32 %[d], %[d], %[t0]\n" \
+    "v_mul_f32 %[t0], %[e1z], %[p2]\n" \
+    "v_add_f32 %[d], %[t0], %[d]\n" \
+    /* collision_detection.h:28-35: leave unless !(d < eps) / !(|d| < eps) */ \
+    "v_and_b32 %[t0], %[dmask], %[d]\n" \
+    "v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n" \
+    "s_cbranch_execz 1f\n" \
+    /* 1 / d (rcp_refined), q = o - a in the shadow of the reciprocal */ \
+    "v_rcp_f32 %[r], %[d]\n" \
+    "v_subrev_f32 %[q0], %[ax], %[ox]\n" \
+    "v_subrev_f32 %[q1], %[ay], %[oy]\n" \
+    "v_subrev_f32 %[q2], %[az], %[oz]\n" \
+    "v_fma_f32 %[e], -%[d], %[r], 1.0\n" \
+    "v_fmac_f32 %[r], %[e], %[r]\n" \
+    "v_fma_f32 %[e], -%[d], %[r], 1.0\n" \
+    "v_fma_f32 %[e], %[e], %[r], %[r]\n" \
+    "v_fma_f32 %[d], -%[d], %[e], 1.0\n" \
+    "v_fmac_f32 %[e], %[d], %[r]\n" \
+    /* u = d_inv * dot(q, p); leave unless !(u < 0) && !(u > 1) */ \
+    "v_mul_f32 %[u], %[q0], %[p0]\n" \
+    "v_mul_f32 %[t0], %[q1], %[p1]\n" \
+    "v_add_f32 %[u], %[u], %[t0]\n" \
+    "v_mul_f32 %[t0], %[q2], %[p2]\n" \
+    "v_add_f32 %[u], %[t0], %[u]\n" \
+    "v_mul_f32 %[u], %[u], %[e]\n" \
+    "v_cmpx_ngt_f32 vcc, 0, %[u]\n" \
+    "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n" \
+    "s_cbranch_execz 1f\n" \
+    /* w = cross(q, e1) */ \
+    "v_mul_f32 %[p0], %[e1z], %[q1]\n" \
+    "v_mul_f32 %[t0], %[e1y], %[q2]\n" \
+    "v_sub_f32 %[p0], %[p0], %[t0]\n" \
+    "v_mul_f32 %[p1], %[e1x], %[q2]\n" \
+    "v_mul_f32 %[t0], %[e1z], %[q0]\n" \
+    "v_sub_f32 %[p1], %[p1], %[t0]\n" \
+    "v_mul_f32 %[p2], %[e1y], %[q0]\n" \
+    "v_mul_f32 %[t0], %[e1x], %[q1]\n" \
+    "v_sub_f32 %[p2], %[p2], %[t0]\n" \
+    /* v = d_inv * dot(w, s); leave unless !(v < 0) && !(u + v > 1) */ \
+    "v_mul_f32 %[d], %[p0], %[sx]\n" \
+    "v_mul_f32 %[t0], %[p1], %[sy]\n" \
+    "v_add_f32 %[d], %[d], %[t0]\n" \
+    "v_mul_f32 %[t0], %[p2], %[sz]\n" \
+    "v_add_f32 %[d], %[t0], %[d]\n" \
+    "v_mul_f32 %[d], %[d], %[e]\n" \
+    "v_add_f32 %[u], %[u], %[d]\n" \
+    "v_cmpx_ngt_f32 vcc, 0, %[d]\n" \
+    "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n" \
+    "s_cbranch_execz 1f\n" \
+    /* t = d_inv * dot(e2, w); an occluder unless t == inf or t < eps (renderer.cc:298), and only below the limit (:302) */ \
+    "v_mul_f32 %[d], %[e2x], %[p0]\n" \
+    "v_mul_f32 %[t0], %[e2y], %[p1]\n" \
+    "v_add_f32 %[d], %[d], %[t0]\n" \
+    "v_mul_f32 %[t0], %[e2z], %[p2]\n" \
+    "v_add_f32 %[d], %[t0], %[d]\n" \
+    "v_mul_f32 %[d], %[d], %[e]\n" \
+    "v_cmpx_neq_f32 vcc, 0x7f800000, %[d]\n" \
+    "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n" \
+    "v_cmpx_lt_f32 vcc, %[d], %[tl]\n" \
+    "s_or_b64 %[found], %[found], exec\n" \
+    "1:\n" \
+    "s_mov_b64 exec, %[save]\n"
+#define RT_ANY_HIT_OUTPUTS                                                                                                      \
+    [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [d] "=&v"(d), [r] "=&v"(r), [e] "=&v"(e), [q0] "=&v"(q0), [q1] "=&v"(q1),     \
+        [q2] "=&v"(q2), [u] "=&v"(u), [t0] "=&v"(t0), [save] "=&s"(save), [found] "+s"(found)
+#define RT_ANY_HIT_INPUTS                                                                                                       \
+    [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] "s"(ax),  \
+        [ay] "s"(ay), [az] "s"(az), [e1x] "s"(e1x), [e1y] "s"(e1y), [e1z] "s"(e1z), [e2x] "s"(e2x), [e2y] "s"(e2y),            \
+        [e2z] "s"(e2z), [tl] "v"(t_limit), [eps] "s"(eps), [dmask] "s"(dmask)
+
+// MASKED = false: tests the lanes of `need`.  MASKED = true: `need` is the set of lanes that carry a ray; the lanes tested
+// are those of them that have no occluder yet and whose `reach` (the leaves the lane reaches) intersects lm (the leaves
+// that list the triangle) -- the selection of the small-tree and clustered passes, folded into the EXEC mask as well.
+template <bool CULL, bool MASKED = false>
 __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax, float ay, float az, float e1x, float e1y, float e1z,
-                                             float e2x, float e2y, float e2z, float t_limit, lanemask& found) {
+                                             float e2x, float e2y, float e2z, float t_limit, lanemask& found, uint32_t reach = 0,
+                                             uint32_t lm = 0) {
     float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
     lanemask save;
     const float eps = kEps;
     const uint32_t dmask = CULL ? 0xffffffffu : 0x7fffffffu;  // the first stage compares d, or |d| when back faces count
-    asm volatile(
-        "s_mov_b64 %[save], exec\n"
-        "s_mov_b64 exec, %[need]\n"
-        // p = cross(s, e2)
-        "v_mul_f32 %[p0], %[e2z], %[sy]\n"
-        "v_mul_f32 %[t0], %[e2y], %[sz]\n"
-        "v_sub_f32 %[p0], %[p0], %[t0]\n"
-        "v_mul_f32 %[p1], %[e2x], %[sz]\n"
-        "v_mul_f32 %[t0], %[e2z], %[sx]\n"
-        "v_sub_f32 %[p1], %[p1], %[t0]\n"
-        "v_mul_f32 %[p2], %[e2y], %[sx]\n"
-        "v_mul_f32 %[t0], %[e2x], %[sy]\n"
-        "v_sub_f32 %[p2], %[p2], %[t0]\n"
-        // d = dot(e1, p)
-        "v_mul_f32 %[d], %[e1x], %[p0]\n"
-        "v_mul_f32 %[t0], %[e1y], %[p1]\n"
-        "v_add_f32 %[d], %[d], %[t0]\n"
-        "v_mul_f32 %[t0], %[e1z], %[p2]\n"
-        "v_add_f32 %[d], %[t0], %[d]\n"
-        // collision_detection.h:28-35: leave unless !(d < eps) / !(|d| < eps)
-        "v_and_b32 %[t0], %[dmask], %[d]\n"
-        "v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n"
-        "s_cbranch_execz 1f\n"
-        // 1 / d (rcp_refined), q = o - a in the shadow of the reciprocal
-        "v_rcp_f32 %[r], %[d]\n"
-        "v_subrev_f32 %[q0], %[ax], %[ox]\n"
-        "v_subrev_f32 %[q1], %[ay], %[oy]\n"
-        "v_subrev_f32 %[q2], %[az], %[oz]\n"
-        "v_fma_f32 %[e], -%[d], %[r], 1.0\n"
-        "v_fmac_f32 %[r], %[e], %[r]\n"
-        "v_fma_f32 %[e], -%[d], %[r], 1.0\n"
-        "v_fma_f32 %[e], %[e], %[r], %[r]\n"
-        "v_fma_f32 %[d], -%[d], %[e], 1.0\n"
-        "v_fmac_f32 %[e], %[d], %[r]\n"
-        // u = d_inv * dot(q, p); leave unless !(u < 0) && !(u > 1)
-        "v_mul_f32 %[u], %[q0], %[p0]\n"
-        "v_mul_f32 %[t0], %[q1], %[p1]\n"
-        "v_add_f32 %[u], %[u], %[t0]\n"
-        "v_mul_f32 %[t0], %[q2], %[p2]\n"
-        "v_add_f32 %[u], %[t0], %[u]\n"
-        "v_mul_f32 %[u], %[u], %[e]\n"
-        "v_cmpx_ngt_f32 vcc, 0, %[u]\n"
-        "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n"
-        "s_cbranch_execz 1f\n"
-        // w = cross(q, e1)
-        "v_mul_f32 %[p0], %[e1z], %[q1]\n"
-        "v_mul_f32 %[t0], %[e1y], %[q2]\n"
-        "v_sub_f32 %[p0], %[p0], %[t0]\n"
-        "v_mul_f32 %[p1], %[e1x], %[q2]\n"
-        "v_mul_f32 %[t0], %[e1z], %[q0]\n"
-        "v_sub_f32 %[p1], %[p1], %[t0]\n"
-        "v_mul_f32 %[p2], %[e1y], %[q0]\n"
-        "v_mul_f32 %[t0], %[e1x], %[q1]\n"
-        "v_sub_f32 %[p2], %[p2], %[t0]\n"
-        // v = d_inv * dot(w, s); leave unless !(v < 0) && !(u + v > 1)
-        "v_mul_f32 %[d], %[p0], %[sx]\n"
-        "v_mul_f32 %[t0], %[p1], %[sy]\n"
-        "v_add_f32 %[d], %[d], %[t0]\n"
-        "v_mul_f32 %[t0], %[p2], %[sz]\n"
-        "v_add_f32 %[d], %[t0], %[d]\n"
-        "v_mul_f32 %[d], %[d], %[e]\n"
-        "v_add_f32 %[u], %[u], %[d]\n"
-        "v_cmpx_ngt_f32 vcc, 0, %[d]\n"
-        "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n"
-        "s_cbranch_execz 1f\n"
-        // t = d_inv * dot(e2, w); an occluder unless t == inf or t < eps (renderer.cc:298), and only below the limit (:302)
-        "v_mul_f32 %[d], %[e2x], %[p0]\n"
-        "v_mul_f32 %[t0], %[e2y], %[p1]\n"
-        "v_add_f32 %[d], %[d], %[t0]\n"
-        "v_mul_f32 %[t0], %[e2z], %[p2]\n"
-        "v_add_f32 %[d], %[t0], %[d]\n"
-        "v_mul_f32 %[d], %[d], %[e]\n"
-        "v_cmpx_neq_f32 vcc, 0x7f800000, %[d]\n"
-        "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n"
-        "v_cmpx_lt_f32 vcc, %[d], %[tl]\n"
-        "s_or_b64 %[found], %[found], exec\n"
-        "1:\n"
-        "s_mov_b64 exec, %[save]\n"
-        : [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [d] "=&v"(d), [r] "=&v"(r), [e] "=&v"(e), [q0] "=&v"(q0), [q1] "=&v"(q1),
-          [q2] "=&v"(q2), [u] "=&v"(u), [t0] "=&v"(t0), [save] "=&s"(save), [found] "+s"(found)
-        : [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] "s"(ax),
-          [ay] "s"(ay), [az] "s"(az), [e1x] "s"(e1x), [e1y] "s"(e1y), [e1z] "s"(e1z), [e2x] "s"(e2x), [e2y] "s"(e2y), [e2z] "s"(e2z),
-          [tl] "v"(t_limit), [eps] "s"(eps), [dmask] "s"(dmask)
-        : "vcc", "scc");
+    if constexpr (MASKED) {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n"
+            "s_andn2_b64 exec, %[need], %[found]\n"
+            "v_and_b32 %[t0], %[lm], %[reach]\n"
+            "v_cmpx_ne_u32 vcc, 0, %[t0]\n"
+            "s_cbranch_execz 1f\n"
+            RT_ANY_HIT_STAGES
+            : RT_ANY_HIT_OUTPUTS
+            : RT_ANY_HIT_INPUTS, [reach] "v"(reach), [lm] "s"(lm)
+            : "vcc", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n"
+            "s_mov_b64 exec, %[need]\n"
+            RT_ANY_HIT_STAGES
+            : RT_ANY_HIT_OUTPUTS
+            : RT_ANY_HIT_INPUTS
+            : "vcc", "scc");
+    }
 }
 
 // Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the
@@ -318,14 +344,14 @@ template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint32_t j, lanemask alive, uint32_t reach, f3 o, f3 d,
                                          float t_limit, HitState& h) {
     const uint32_t lm = RT_W(blk, 12 * jj + 10);
-    const lanemask need = alive & ballot64((reach & lm) != 0);
-    if (need == 0) return;
-    if constexpr (ANY && FAST) {
-        any_hit_exec<CULL>(need, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
-                           RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8),
-                           t_limit, h.found);
+    if constexpr (ANY && FAST) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
+        any_hit_exec<CULL, true>(alive, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
+                                 RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7),
+                                 RT_F(blk, 12 * jj + 8), t_limit, h.found, reach, lm);
         return;
     }
+    const lanemask need = alive & ballot64((reach & lm) != 0);
+    if (need == 0) return;
     const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
     const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
     const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
@@ -352,10 +378,10 @@ __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uin
     // The array is padded to whole blocks with records whose leaf mask is 0: no lane ever needs them.
     for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)j0 * 12);
-        flat_one<ANY, CULL, FAST>(blk, 0, j0 + 0, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 1, j0 + 1, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 2, j0 + 2, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 3, j0 + 3, ANY ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 0, j0 + 0, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 1, j0 + 1, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 2, j0 + 2, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 3, j0 + 3, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
         if (ANY && (all & ~h.found) == 0) return;  // every ray of the wave is decided
     }
 }
@@ -483,18 +509,19 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, ui
         RT_WPROF(13, 1);
         return;
     }
+    if constexpr (FAST) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
+        RT_WPROF(15, 1);
+        any_hit_exec<CULL, true>(alive, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
+                                 RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7),
+                                 RT_F(blk, 12 * jj + 8), t_limit, h.found, reach, lm);
+        return;
+    }
     const lanemask need = alive & ballot64((reach & lm) != 0);
     if (need == 0) {
         RT_WPROF(14, 1);
         return;
     }
     RT_WPROF(15, 1);
-    if constexpr (FAST) {
-        any_hit_exec<CULL>(need, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
-                           RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8),
-                           t_limit, h.found);
-        return;
-    }
     const f3 a = mk(RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2));
     const f3 e1 = mk(RT_F(blk, 12 * jj + 3), RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5));
     const f3 e2 = mk(RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7), RT_F(blk, 12 * jj + 8));
@@ -562,10 +589,10 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
                 if (wreach != 0) {
                     for (uint32_t k0 = 0; k0 < list_count && (all & ~h.found) != 0; k0 += kTriChunk) {
                         const Block48 blk = sload48(tris + (size_t)(list_begin + k0) * 12);
-                        cluster_one<CULL, FAST>(blk, 0, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 1, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 2, wreach, all & ~h.found, reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 3, wreach, all & ~h.found, reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 0, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 1, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 2, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 3, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
                     }
                     wreach = 0;
                 }
