@@ -97,10 +97,12 @@ int rt_ads_build(rt_ads* ads, const float* positions, uint64_t n_triangles);
 int rt_ads_export_tree(const rt_ads* ads, void* node_records, void* leaf_slots, uint32_t* root_info2, uint64_t* n_records,
                        uint64_t* n_slots, uint32_t* max_stack, int* built_on_device);
 
-/* Which optional forms of the tree are resident beside the plain records (both serve the wave-together kernels and
- * leave the candidate sets of octree.cc:186-191 unchanged): small_tree_triangles > 0 = the small-tree form (<= 32 leaves,
- * <= 1024 triangles), clusters > 0 = the clustered form for any-hit rays.  Either pointer may be NULL. */
-int rt_ads_tree_forms(const rt_ads* ads, uint64_t* small_tree_triangles, uint32_t* clusters);
+/* Which optional forms serve the wave-together kernels on this tree (none of them changes the candidate sets of
+ * octree.cc:186-191 or a result bit): small_tree_triangles > 0 = the small-tree form is resident (<= 32 leaves,
+ * <= 1024 triangles), clusters > 0 = the clustered form for any-hit rays is resident, fast_any_hit = 1 if every
+ * triangle has |e1| * |e2| < 2^30, so that the any-hit triangle test of shadow rays (unit directions) never needs the
+ * full division and runs its hand-scheduled form.  Any pointer may be NULL. */
+int rt_ads_tree_forms(const rt_ads* ads, uint64_t* small_tree_triangles, uint32_t* clusters, int* fast_any_hit);
 
 /* Octree::PrintStats / calculate_stats, structural part (src/ADS/Octree/octree.cc:209-266). */
 typedef struct rt_tree_stats {

@@ -102,7 +102,7 @@ def lib():
     L.rt_ads_destroy.restype = None
     L.rt_ads_build.argtypes = [vp, vp, C.c_uint64]
     L.rt_ads_export_tree.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
-    L.rt_ads_tree_forms.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.rt_ads_tree_forms.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
     L.rt_ads_reset_query_stats.argtypes = [vp]

@@ -191,10 +191,11 @@ class GpuOctree(Ads):
         return nodes, slots, (int(root[0]), int(root[1])), int(ms.value), bool(dev.value)
 
     def tree_forms(self):
-        """(triangles of the small-tree form, clusters of the clustered form); 0 = that form is not resident."""
-        a, b = C.c_uint64(), C.c_uint32()
-        _capi.check(_capi.lib().rt_ads_tree_forms(self._h, C.byref(a), C.byref(b)))
-        return int(a.value), int(b.value)
+        """(triangles of the small-tree form, clusters of the clustered form, hand-scheduled any-hit test in use);
+        0 = that form is not in use on this tree."""
+        a, b, c = C.c_uint64(), C.c_uint32(), C.c_int()
+        _capi.check(_capi.lib().rt_ads_tree_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def tree_stats(self):
         st = _capi.TreeStats()

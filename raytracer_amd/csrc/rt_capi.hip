@@ -882,11 +882,12 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     return RT_OK;
 }
 
-int rt_ads_tree_forms(const rt_ads* a, uint64_t* small_tree_triangles, uint32_t* clusters) {
+int rt_ads_tree_forms(const rt_ads* a, uint64_t* small_tree_triangles, uint32_t* clusters, int* fast_any_hit) {
     if (!a) return fail(RT_ERR_INVALID, "null argument");
     if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
     if (small_tree_triangles) *small_tree_triangles = a->use_flat ? a->n_flat_tris : 0;
     if (clusters) *clusters = a->use_clusters ? a->n_clusters : 0u;
+    if (fast_any_hit) *fast_any_hit = a->fast_tri ? 1 : 0;
     return RT_OK;
 }
 
@@ -1162,9 +1163,18 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     const int mode = traversal_mode(a, false, true, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
-    if (mode == MODE_CLUSTER) {
-        if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER>), grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
-        else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER>), grid, block, 0, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+    if (mode == MODE_CLUSTER || (mode == MODE_WAVE && a->fast_tri)) {
+        const DevOctree T = dev_tree(a);
+        if (mode == MODE_CLUSTER && a->fast_tri) {
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+        } else if (mode == MODE_CLUSTER) {
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+        } else {
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+        }
     } else {
         RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
     }

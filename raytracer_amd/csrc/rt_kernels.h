@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
     }
 }
 
-template <bool CULL, int MODE>
+template <bool CULL, int MODE, bool FAST = false>  // FAST: see trace<> (the directions are normalised here)
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
                                                    uint64_t n, uint8_t* __restrict__ out, uint32_t sparse) {
     bool lane_ok;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const f3 d = normalize(pl);
     __shared__ TraverseLds<MODE> lds[4];
     HitState h;
-    trace<true, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, p, d, dist, h);
+    trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], valid, p, d, dist, h);
     if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 

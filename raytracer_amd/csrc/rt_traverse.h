@@ -251,8 +251,10 @@ __device__ __forceinline__ bool ray_box(f3 o, f3 inv, float bx0, float by0, floa
 // them listed by no reached leaf, 14 of them needed by no live lane, 15 triangle tests started.
 __device__ unsigned long long g_wave_prof[16];
 #define RT_WPROF(k, v) do { if (__lane_id() == 0) atomicAdd(&g_wave_prof[k], (unsigned long long)(v)); } while (0)
+constexpr bool kHandScheduledTests = false;  // (the counters' lane branches and the ISA block's scalar operands do not mix)
 #else
 #define RT_WPROF(k, v) do { } while (0)
+constexpr bool kHandScheduledTests = true;
 #endif
 
 struct HitState {
@@ -289,7 +291,7 @@ __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32
                                          HitState& h) {
     if (mine == 0) return;
     if (ANY) RT_WPROF(3, 1);
-    if constexpr (ANY && FAST) {
+    if constexpr (ANY && FAST && kHandScheduledTests) {
         any_hit_exec<CULL>(mine, o, d, RT_F(blk, 12 * j + 0), RT_F(blk, 12 * j + 1), RT_F(blk, 12 * j + 2), RT_F(blk, 12 * j + 3),
                            RT_F(blk, 12 * j + 4), RT_F(blk, 12 * j + 5), RT_F(blk, 12 * j + 6), RT_F(blk, 12 * j + 7), RT_F(blk, 12 * j + 8),
                            t_limit, h.found);
@@ -344,7 +346,7 @@ template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint32_t j, lanemask alive, uint32_t reach, f3 o, f3 d,
                                          float t_limit, HitState& h) {
     const uint32_t lm = RT_W(blk, 12 * jj + 10);
-    if constexpr (ANY && FAST) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
+    if constexpr (ANY && FAST && kHandScheduledTests) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
         any_hit_exec<CULL, true>(alive, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
                                  RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7),
                                  RT_F(blk, 12 * jj + 8), t_limit, h.found, reach, lm);
@@ -378,10 +380,10 @@ __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uin
     // The array is padded to whole blocks with records whose leaf mask is 0: no lane ever needs them.
     for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)j0 * 12);
-        flat_one<ANY, CULL, FAST>(blk, 0, j0 + 0, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 1, j0 + 1, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 2, j0 + 2, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
-        flat_one<ANY, CULL, FAST>(blk, 3, j0 + 3, (ANY && !FAST) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 0, j0 + 0, (ANY && !(FAST && kHandScheduledTests)) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 1, j0 + 1, (ANY && !(FAST && kHandScheduledTests)) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 2, j0 + 2, (ANY && !(FAST && kHandScheduledTests)) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
+        flat_one<ANY, CULL, FAST>(blk, 3, j0 + 3, (ANY && !(FAST && kHandScheduledTests)) ? (all & ~h.found) : all, reach, o, d, t_limit, h);
         if (ANY && (all & ~h.found) == 0) return;  // every ray of the wave is decided
     }
 }
@@ -509,7 +511,7 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, ui
         RT_WPROF(13, 1);
         return;
     }
-    if constexpr (FAST) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
+    if constexpr (FAST && kHandScheduledTests) {  // (alive: every lane with a ray; the test leaves out those that have an occluder)
         RT_WPROF(15, 1);
         any_hit_exec<CULL, true>(alive, o, d, RT_F(blk, 12 * jj + 0), RT_F(blk, 12 * jj + 1), RT_F(blk, 12 * jj + 2), RT_F(blk, 12 * jj + 3),
                                  RT_F(blk, 12 * jj + 4), RT_F(blk, 12 * jj + 5), RT_F(blk, 12 * jj + 6), RT_F(blk, 12 * jj + 7),
@@ -589,10 +591,10 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
                 if (wreach != 0) {
                     for (uint32_t k0 = 0; k0 < list_count && (all & ~h.found) != 0; k0 += kTriChunk) {
                         const Block48 blk = sload48(tris + (size_t)(list_begin + k0) * 12);
-                        cluster_one<CULL, FAST>(blk, 0, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 1, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 2, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
-                        cluster_one<CULL, FAST>(blk, 3, wreach, FAST ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 0, wreach, (FAST && kHandScheduledTests) ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 1, wreach, (FAST && kHandScheduledTests) ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 2, wreach, (FAST && kHandScheduledTests) ? all : (all & ~h.found), reach, o, d, t_limit, h);
+                        cluster_one<CULL, FAST>(blk, 3, wreach, (FAST && kHandScheduledTests) ? all : (all & ~h.found), reach, o, d, t_limit, h);
                     }
                     wreach = 0;
                 }

@@ -190,11 +190,19 @@ def test_clustered_any_hit_form(rt, orc, scenes, monkeypatch, scene, mb, md):
     monkeypatch.setenv("RT_TRAVERSAL", "wave")
     monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
     monkeypatch.setenv("RT_DISABLE_CLUSTERS", "1")
+    monkeypatch.setenv("RT_DISABLE_FAST_TRI", "1")
     g_plain = build(rt, sc, mb, md)
-    assert g_plain.tree_forms() == (0, 0)
+    assert g_plain.tree_forms() == (0, 0, 0)
     monkeypatch.delenv("RT_DISABLE_CLUSTERS")
-    g = build(rt, sc, mb, md)
-    assert g.tree_forms()[0] == 0 and g.tree_forms()[1] > 0
+    g_compiled = build(rt, sc, mb, md)  # clustered walk, compiled triangle test
+    assert g_compiled.tree_forms()[1:] == (g_compiled.tree_forms()[1], 0) and g_compiled.tree_forms()[1] > 0
+    monkeypatch.delenv("RT_DISABLE_FAST_TRI")
+    g = build(rt, sc, mb, md)  # clustered walk, hand-scheduled triangle test
+    assert g.tree_forms()[0] == 0 and g.tree_forms()[1] > 0 and g.tree_forms()[2] == 1
+    monkeypatch.setenv("RT_DISABLE_CLUSTERS", "1")
+    g_plain_fast = build(rt, sc, mb, md)  # plain walk, hand-scheduled triangle test
+    assert g_plain_fast.tree_forms() == (0, 0, 1)
+    monkeypatch.delenv("RT_DISABLE_CLUSTERS")
     ot = orc.Octree(sc, mb, md)
     o, d = random_rays(sc, 40000, 23)
     t_ref, tri_ref = ot.trace_closest(o, d, False)
@@ -217,8 +225,8 @@ def test_clustered_any_hit_form(rt, orc, scenes, monkeypatch, scene, mb, md):
             for n in (len(Pc), 65, 1):
                 for cull in (True, False):
                     ref = ot.trace_any(Pc[:n], Lc[:n], cull)
-                    assert np.array_equal(g.trace_any(Pc[:n], Lc[:n], cull), ref)
-                    assert np.array_equal(g_plain.trace_any(Pc[:n], Lc[:n], cull), ref)
+                    for other in (g, g_plain, g_compiled, g_plain_fast):
+                        assert np.array_equal(other.trace_any(Pc[:n], Lc[:n], cull), ref)
         occ = ot.trace_any(cases[0][0], cases[0][1], True)
         assert 0 < occ.sum() < occ.size
     if scene in ("sphere", "original"):
@@ -230,6 +238,46 @@ def test_clustered_any_hit_form(rt, orc, scenes, monkeypatch, scene, mb, md):
         assert np.array_equal(bits(img), bits(img_p)) and st.rays == st_p.rays and st.shadow_rays > 0
         ref, _, _, ost = orc.render(sc, ot, orc.make_cfg(rng_mode=orc.RNG_COUNTER, **{**kw, "aspect_mode": orc.ASPECT_TRUE}), want_hits=False)
         assert np.abs(img - ref).max() <= 1.0 / 255.0 and st.rays == ost.search_calls
+
+
+def test_hand_scheduled_any_hit_test_and_its_range_gate(rt, orc, scenes, monkeypatch):
+    """Shadow rays of scenes whose triangles are small enough use a triangle test whose reciprocal never takes the full
+    division; it must give the oracle's flags in the small-tree pass too, and a scene beyond the bound (edges of 1e8
+    units: |e1| * |e2| > 2^30) must fall back to the compiled test by itself."""
+    sc = scenes["original"]
+    ot = orc.Octree(sc, 16, 10)
+    o, d = random_rays(sc, 30000, 31)
+    t_ref, tri_ref = ot.trace_closest(o, d, False)
+    hit = tri_ref >= 0
+    P = (o[hit] + d[hit] * t_ref[hit, None]).astype(np.float32)
+    rs = np.random.RandomState(9)
+    lt = sc.pos[sc.light_tri[rs.randint(0, sc.n_light, P.shape[0])]]
+    L = (lt[:, 0] * 0.5 + lt[:, 1] * 0.2 + lt[:, 2] * 0.3).astype(np.float32)
+    L[::5] = P[::5]                       # zero-length segments
+    L[1::7, 1] = np.inf                   # infinite and NaN targets
+    L[2::11, 0] = np.nan
+    for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_DISABLE_FAST_TRI"):
+        monkeypatch.delenv(k, raising=False)
+    g_fast = build(rt, sc)
+    assert g_fast.tree_forms()[0] > 0 and g_fast.tree_forms()[2] == 1
+    monkeypatch.setenv("RT_DISABLE_FAST_TRI", "1")
+    g_compiled = build(rt, sc)
+    assert g_compiled.tree_forms()[2] == 0
+    monkeypatch.delenv("RT_DISABLE_FAST_TRI")
+    with np.errstate(all="ignore"):
+        for cull in (True, False):
+            ref = ot.trace_any(P, L, cull)
+            assert np.array_equal(g_fast.trace_any(P, L, cull), ref) and np.array_equal(g_compiled.trace_any(P, L, cull), ref)
+        assert 0 < ref.sum() < ref.size
+    # the same scene scaled by 1e6: the bound fails, results still equal the oracle's
+    big = orc.Scene.from_arrays((sc.pos * np.float32(1e6)).astype(np.float32), None, sc.matid, sc.materials)
+    g_big = build(rt, big)
+    assert g_big.tree_forms()[2] == 0
+    ot_big = orc.Octree(big, 16, 10)
+    Pb, Lb = (P * np.float32(1e6)).astype(np.float32), (L * np.float32(1e6)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        for cull in (True, False):
+            assert np.array_equal(g_big.trace_any(Pb, Lb, cull), ot_big.trace_any(Pb, Lb, cull))
 
 
 @pytest.mark.parametrize("mode", ["wave", "lane", "pool"])
