@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run on the GPU box from the repository root: everything behind profiles/<tag>_*: the counter passes of the three
+# single-GPU workloads (tools/pmc_profile.sh -> gpurun_out/profiles_new/), one default bench run
+# (gpurun_out/bench_default.json) and one rank's share of 1/2/4/8-way splits of every workload (gpurun_out/band_times.txt).
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+timeout -k 10 900 bash tools/pmc_profile.sh r02 > gpurun_out/pmc_profile.log 2>&1
+echo pmc done
+timeout -k 10 300 python3 bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+echo bench done
+: > gpurun_out/band_times.txt
+for w in cornell_original_blinn_spt16_1080p synthetic_ico8_phong_4k cornell_sphere_blinn_smooth_spp4_1080p; do
+  timeout -k 10 200 python3 tools/band_time.py $w >> gpurun_out/band_times.txt 2>/dev/null
+done
+BAND_WORLDS=1,8 BAND_FRAMES=2 timeout -k 10 200 python3 tools/band_time.py cornell_original_blinn_spp64_spt32_4k >> gpurun_out/band_times.txt 2>/dev/null
+echo band done
