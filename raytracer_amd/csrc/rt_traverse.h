@@ -373,6 +373,53 @@ __device__ __forceinline__ void flat_one(const Block48& blk, const int jj, uint3
     }
 }
 
+#ifdef RT_LDS_STAGED_TRIS
+// Measurement variant (tools/ab.sh): the same pass with the triangle batches staged through LDS -- 48 lanes fetch the 48
+// dwords of a 4-record block with one coalesced vector load, write them to the wave's LDS buffer, and every operand of
+// the tests is read back from LDS (same address in all lanes: a broadcast) into vector registers -- instead of scalar
+// loads that feed the VALU from scalar registers.
+template <bool ANY, bool CULL, bool FAST = false>
+__device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
+    __shared__ uint32_t stage_all[16][48];
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_word;
+    lds_word* stage = (lds_word*)stage_all[threadIdx.x >> 6];
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(T.flat_tris);
+    const uint32_t lane = __lane_id();
+    const uint32_t n = T.n_flat_tris;
+    for (uint32_t j0 = 0; j0 < n; j0 += kTriChunk) {
+        uint32_t w = 0;
+        if (lane < 48) w = base[(size_t)j0 * 12 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) stage[lane] = w;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const lanemask alive = ANY ? (all & ~h.found) : all;
+            const uint32_t lm = stage[12 * jj + 10];
+            const lanemask need = alive & ballot64((reach & lm) != 0);
+            if (need == 0) continue;
+            const f3 a = mk(__uint_as_float(stage[12 * jj + 0]), __uint_as_float(stage[12 * jj + 1]), __uint_as_float(stage[12 * jj + 2]));
+            const f3 e1 = mk(__uint_as_float(stage[12 * jj + 3]), __uint_as_float(stage[12 * jj + 4]), __uint_as_float(stage[12 * jj + 5]));
+            const f3 e2 = mk(__uint_as_float(stage[12 * jj + 6]), __uint_as_float(stage[12 * jj + 7]), __uint_as_float(stage[12 * jj + 8]));
+            float t = RT_INF;
+            const lanemask hit = ray_triangle<CULL>(need, o, d, a, e1, e2, t);
+            if (hit == 0) continue;
+            if (ANY) {
+                h.found |= hit & ballot64(t < t_limit);
+            } else {
+                const uint32_t first_leaf = (uint32_t)__builtin_ctz(reach & lm);
+                const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(first_leaf < h.slot)));
+                if (better == 0) continue;
+                const bool b = lane_of(better);
+                h.t = b ? t : h.t;
+                h.slot = b ? first_leaf : h.slot;
+                h.tri = b ? (j0 + jj) : h.tri;
+            }
+        }
+        if (ANY && (all & ~h.found) == 0) return;
+    }
+}
+#else
 template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uint32_t reach, f3 o, f3 d, float t_limit, HitState& h) {
     cu32_p base = as_const_u(T.flat_tris);
@@ -387,6 +434,8 @@ __device__ __forceinline__ void flat_tests(const DevOctree& T, lanemask all, uin
         if (ANY && (all & ~h.found) == 0) return;  // every ray of the wave is decided
     }
 }
+
+#endif
 
 // The wave-uniform traversal stack: entry i lives in lane (i & 63) of register (i >> 6) of each field.
 // An entry is one octant that some lanes reach: its NodeRec::info pair and the mask of those lanes.
