@@ -103,7 +103,7 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 // full division.  rec: a, e1, e2 in wave-uniform registers.
 // The stages of the test, entered with EXEC = the lanes to test; leaves through label 1 with EXEC = the lanes that found
 // an occluder already or-ed into %[found].
-#define RT_ANY_HIT_STAGES \
+#define RT_ANY_HIT_STAGES(FIRST_STAGE) \
     /* p = cross(s, e2) */ \
     "v_mul_f32 %[p0], %[e2z], %[sy]\n" \
     "v_mul_f32 %[t0], %[e2y], %[sz]\n" \
@@ -121,8 +121,7 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
     "v_mul_f32 %[t0], %[e1z], %[p2]\n" \
     "v_add_f32 %[d], %[t0], %[d]\n" \
     /* collision_detection.h:28-35: leave unless !(d < eps) / !(|d| < eps) */ \
-    "v_and_b32 %[t0], %[dmask], %[d]\n" \
-    "v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n" \
+    FIRST_STAGE \
     "s_cbranch_execz 1f\n" \
     /* 1 / d (rcp_refined), q = o - a in the shadow of the reciprocal */ \
     "v_rcp_f32 %[r], %[d]\n" \
@@ -185,8 +184,10 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 #define RT_ANY_HIT_INPUTS                                                                                                       \
     [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] "s"(ax),  \
         [ay] "s"(ay), [az] "s"(az), [e1x] "s"(e1x), [e1y] "s"(e1y), [e1z] "s"(e1z), [e2x] "s"(e2x), [e2y] "s"(e2y),            \
-        [e2z] "s"(e2z), [tl] "v"(t_limit), [eps] "s"(eps), [dmask] "s"(dmask)
+        [e2z] "s"(e2z), [tl] "v"(t_limit), [eps] "s"(eps)
 
+#define RT_ANY_HIT_CULL "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n"                                         /* !(d < eps) */
+#define RT_ANY_HIT_NOCULL "v_and_b32 %[t0], 0x7fffffff, %[d]\n v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n" /* !(|d| < eps) */
 // MASKED = false: tests the lanes of `need`.  MASKED = true: `need` is the set of lanes that carry a ray; the lanes tested
 // are those of them that have no occluder yet and whose `reach` (the leaves the lane reaches) intersects lm (the leaves
 // that list the triangle) -- the selection of the small-tree and clustered passes, folded into the EXEC mask as well.
@@ -197,27 +198,21 @@ __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax
     float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
     lanemask save;
     const float eps = kEps;
-    const uint32_t dmask = CULL ? 0xffffffffu : 0x7fffffffu;  // the first stage compares d, or |d| when back faces count
-    if constexpr (MASKED) {
-        asm volatile(
-            "s_mov_b64 %[save], exec\n"
-            "s_andn2_b64 exec, %[need], %[found]\n"
-            "v_and_b32 %[t0], %[lm], %[reach]\n"
-            "v_cmpx_ne_u32 vcc, 0, %[t0]\n"
-            "s_cbranch_execz 1f\n"
-            RT_ANY_HIT_STAGES
-            : RT_ANY_HIT_OUTPUTS
-            : RT_ANY_HIT_INPUTS, [reach] "v"(reach), [lm] "s"(lm)
-            : "vcc", "scc");
-    } else {
-        asm volatile(
-            "s_mov_b64 %[save], exec\n"
-            "s_mov_b64 exec, %[need]\n"
-            RT_ANY_HIT_STAGES
-            : RT_ANY_HIT_OUTPUTS
-            : RT_ANY_HIT_INPUTS
-            : "vcc", "scc");
-    }
+#define RT_ANY_HIT_ASM(PROLOGUE, FIRST_STAGE, EXTRA_INPUTS)                                     \
+    asm volatile("s_mov_b64 %[save], exec\n" PROLOGUE RT_ANY_HIT_STAGES(FIRST_STAGE)            \
+                 : RT_ANY_HIT_OUTPUTS                                                            \
+                 : RT_ANY_HIT_INPUTS EXTRA_INPUTS                                                \
+                 : "vcc", "scc")
+#define RT_ANY_HIT_MASKED_PROLOGUE                \
+    "s_andn2_b64 exec, %[need], %[found]\n"       \
+    "v_and_b32 %[t0], %[lm], %[reach]\n"          \
+    "v_cmpx_ne_u32 vcc, 0, %[t0]\n"               \
+    "s_cbranch_execz 1f\n"
+#define RT_ANY_HIT_MASKED_INPUTS , [reach] "v"(reach), [lm] "s"(lm)
+    if constexpr (MASKED && CULL) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_CULL, RT_ANY_HIT_MASKED_INPUTS);
+    else if constexpr (MASKED) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_NOCULL, RT_ANY_HIT_MASKED_INPUTS);
+    else if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, );
+    else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, );
 }
 
 // Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the
