@@ -188,16 +188,7 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 
 #define RT_ANY_HIT_CULL "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n"                                         /* !(d < eps) */
 #define RT_ANY_HIT_NOCULL "v_and_b32 %[t0], 0x7fffffff, %[d]\n v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n" /* !(|d| < eps) */
-// MASKED = false: tests the lanes of `need`.  MASKED = true: `need` is the set of lanes that carry a ray; the lanes tested
-// are those of them that have no occluder yet and whose `reach` (the leaves the lane reaches) intersects lm (the leaves
-// that list the triangle) -- the selection of the small-tree and clustered passes, folded into the EXEC mask as well.
-template <bool CULL, bool MASKED = false>
-__device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax, float ay, float az, float e1x, float e1y, float e1z,
-                                             float e2x, float e2y, float e2z, float t_limit, lanemask& found, uint32_t reach = 0,
-                                             uint32_t lm = 0) {
-    float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
-    lanemask save;
-    const float eps = kEps;
+// One asm statement: save EXEC, select the lanes (PROLOGUE), run the stages, restore EXEC.
 #define RT_ANY_HIT_ASM(PROLOGUE, FIRST_STAGE, EXTRA_INPUTS)                                     \
     asm volatile("s_mov_b64 %[save], exec\n" PROLOGUE RT_ANY_HIT_STAGES(FIRST_STAGE)            \
                  : RT_ANY_HIT_OUTPUTS                                                            \
@@ -209,6 +200,16 @@ __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax
     "v_cmpx_ne_u32 vcc, 0, %[t0]\n"               \
     "s_cbranch_execz 1f\n"
 #define RT_ANY_HIT_MASKED_INPUTS , [reach] "v"(reach), [lm] "s"(lm)
+// MASKED = false: tests the lanes of `need`.  MASKED = true: `need` is the set of lanes that carry a ray; the lanes tested
+// are those of them that have no occluder yet and whose `reach` (the leaves the lane reaches) intersects lm (the leaves
+// that list the triangle) -- the selection of the small-tree and clustered passes, folded into the EXEC mask as well.
+template <bool CULL, bool MASKED = false>
+__device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax, float ay, float az, float e1x, float e1y, float e1z,
+                                             float e2x, float e2y, float e2z, float t_limit, lanemask& found, uint32_t reach = 0,
+                                             uint32_t lm = 0) {
+    float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
+    lanemask save;
+    const float eps = kEps;
     if constexpr (MASKED && CULL) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_CULL, RT_ANY_HIT_MASKED_INPUTS);
     else if constexpr (MASKED) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_NOCULL, RT_ANY_HIT_MASKED_INPUTS);
     else if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, );
