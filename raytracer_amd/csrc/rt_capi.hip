@@ -135,29 +135,19 @@ constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots ar
 
 template <class... Args>
 void launch_shadow(bool cull, int mode, bool fast_tri, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
-    if (fast_tri && mode == MODE_CLUSTER) {
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_CLUSTER, 4, true>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_CLUSTER, 4, true>), grid, block, 0, stream, args...);
-        return;
+#define RT_SHADOW_CASE(MODE, WAVES)                                                                                          \
+    if (mode == MODE) {                                                                                                      \
+        if (fast_tri && cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, true>), grid, block, 0, stream, args...);       \
+        else if (fast_tri) hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, true>), grid, block, 0, stream, args...);         \
+        else if (cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, false>), grid, block, 0, stream, args...);             \
+        else hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, false>), grid, block, 0, stream, args...);                      \
+        return;                                                                                                              \
     }
-    if (fast_tri && mode == MODE_WAVE) {
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_WAVE, 4, true>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_WAVE, 4, true>), grid, block, 0, stream, args...);
-        return;
-    }
-    if (mode == MODE_POOL) {  // one-wave blocks
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_POOL, 1>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_POOL, 1>), grid, block, 0, stream, args...);
-    } else if (mode == MODE_LANE) {  // one-wave blocks
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_LANE, 1>), grid, block, 0, stream, args...);
-    } else if (mode == MODE_CLUSTER) {
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_CLUSTER, 4>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_CLUSTER, 4>), grid, block, 0, stream, args...);
-    } else {
-        if (cull) hipLaunchKernelGGL((k_shadow<true, MODE_WAVE, 4>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_shadow<false, MODE_WAVE, 4>), grid, block, 0, stream, args...);
-    }
+    RT_SHADOW_CASE(MODE_POOL, 1)   // one-wave blocks
+    RT_SHADOW_CASE(MODE_LANE, 1)   // one-wave blocks
+    RT_SHADOW_CASE(MODE_CLUSTER, 4)
+    RT_SHADOW_CASE(MODE_WAVE, 4)
+#undef RT_SHADOW_CASE
 }
 
 }  // namespace
@@ -210,6 +200,7 @@ struct rt_ads {
     TreeShape shape;
     DevBuf<NodeRec> d_nodes;
     DevBuf<LeafTri> d_slots, d_tri_geom, d_flat_tris;
+    DevBuf<float> d_slot_geom;  // 9 floats per leaf slot (DevOctree::slot_geom)
     DevBuf<NodeRec> d_flat_nodes;
     // clustered form (ClusterForm in host_octree.h): any-hit walks of trees that stay in the wave-together form
     DevBuf<NodeRec> d_cl_nodes;
@@ -260,6 +251,7 @@ DevOctree dev_tree(const rt_ads* a) {
     t.cl_nodes = clustered ? a->d_cl_nodes.p : nullptr;
     t.cl_tris = clustered ? a->d_cl_tris.p : nullptr;
     t.cl_root_info1 = a->cl_root_info1;
+    t.slot_geom = a->d_slot_geom.p;
     return t;
 }
 
@@ -543,7 +535,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
 void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
-    a->d_nodes.release(); a->d_slots.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
+    a->d_nodes.release(); a->d_slots.release(); a->d_slot_geom.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
     for (auto& l : a->levels) l.release();
     a->search.release();
@@ -878,6 +870,14 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->use_clusters = true;
     if (const char* e = getenv("RT_DISABLE_CLUSTERS")) a->use_clusters = !(e[0] == '1');
     if (int rc = make_cluster_form(a)) return rc;
+    // the slots' geometry alone, for the forms that read it per lane
+    HIP_TRY(a->d_slot_geom.reserve((size_t)std::max<uint64_t>(a->n_slots, 1) * 9));
+    if (a->n_slots) {
+        hipLaunchKernelGGL(k_pack_slot_geometry, dim3((unsigned)((a->n_slots + 255) / 256)), dim3(256), 0, 0, a->d_slots.p, (uint32_t)a->n_slots,
+                           a->d_slot_geom.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(0));
+    }
     a->built = true;
     return RT_OK;
 }
@@ -922,7 +922,7 @@ int rt_ads_tree_stats(const rt_ads* a, rt_tree_stats* out) {
     out->leaf_refs = a->shape.leaf_refs;
     out->internal_nodes = a->shape.internal;
     out->build_seconds = a->build_seconds;
-    out->device_bytes = a->n_rec * sizeof(NodeRec) + a->n_slots * sizeof(LeafTri) + a->n_tri * sizeof(LeafTri);
+    out->device_bytes = a->n_rec * sizeof(NodeRec) + a->n_slots * (sizeof(LeafTri) + 9 * sizeof(float)) + a->n_tri * sizeof(LeafTri);
     return RT_OK;
 }
 

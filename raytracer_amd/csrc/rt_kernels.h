@@ -63,6 +63,17 @@ template <>
 struct TraverseLds<MODE_POOL> {
     PoolLds s;
 };
+// a, e1, e2 of every leaf slot as 9 consecutive floats (DevOctree::slot_geom).
+__global__ void __launch_bounds__(256) k_pack_slot_geometry(const LeafTri* __restrict__ slots, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LeafTri s = slots[i];
+    float* g = out + (size_t)i * 9;
+    g[0] = s.ax; g[1] = s.ay; g[2] = s.az;
+    g[3] = s.e1x; g[4] = s.e1y; g[5] = s.e1z;
+    g[6] = s.e2x; g[7] = s.e2y; g[8] = s.e2z;
+}
+
 // Thread index -> ray index: one ray per lane, and only the first 64 >> sparse lanes of a wave carry rays (sparse > 0:
 // small launches of the pool form, whose idle lanes still work on the wave's tasks -- more, shorter waves).
 // ok: the lane carries a ray.
@@ -71,11 +82,11 @@ __device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool&
     ok = lane < (64u >> sparse);
     return ((g >> 6) << (6u - sparse)) + lane;
 }
-// FAST: any-hit rays with unit-length directions in a scene within the bound of any_hit_exec (wave-together forms only).
+// FAST: any-hit rays with unit-length directions in a scene within the bound of any_hit_exec.
 template <bool ANY, bool CULL, int MODE, bool FAST = false>
 __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
-    else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL>(T, lds.s, valid, o, d, t_limit, h);
+    if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, h);
+    else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, h);
     else if constexpr (MODE == MODE_CLUSTER) {
         static_assert(ANY, "the clustered form serves any-hit queries");
         traverse_any_clustered<CULL, FAST>(T, valid, o, d, t_limit, h);

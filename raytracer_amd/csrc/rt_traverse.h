@@ -47,6 +47,10 @@ struct DevOctree {
     const NodeRec* cl_nodes;
     const LeafTri* cl_tris;
     uint32_t cl_root_info1;
+    // The geometry of the leaf slots alone, 9 floats (a, e1, e2) per slot: what the per-lane and task-pool forms read.
+    // Their pair tests fetch every record from beyond the L2 (a big tree's slots are read with next to no reuse there),
+    // so the kernel's time follows the bytes per record: 36 instead of 48.
+    const float* slot_geom;
 };
 
 typedef const RT_CONST float* cfloat_p;
@@ -181,18 +185,18 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 #define RT_ANY_HIT_OUTPUTS                                                                                                      \
     [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [d] "=&v"(d), [r] "=&v"(r), [e] "=&v"(e), [q0] "=&v"(q0), [q1] "=&v"(q1),     \
         [q2] "=&v"(q2), [u] "=&v"(u), [t0] "=&v"(t0), [save] "=&s"(save), [found] "+s"(found)
-#define RT_ANY_HIT_INPUTS                                                                                                       \
-    [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] "s"(ax),  \
-        [ay] "s"(ay), [az] "s"(az), [e1x] "s"(e1x), [e1y] "s"(e1y), [e1z] "s"(e1z), [e2x] "s"(e2x), [e2y] "s"(e2y),            \
-        [e2z] "s"(e2z), [tl] "v"(t_limit), [eps] "s"(eps)
+#define RT_ANY_HIT_INPUTS(REC)                                                                                                  \
+    [need] "s"(need), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [ax] REC(ax),  \
+        [ay] REC(ay), [az] REC(az), [e1x] REC(e1x), [e1y] REC(e1y), [e1z] REC(e1z), [e2x] REC(e2x), [e2y] REC(e2y),            \
+        [e2z] REC(e2z), [tl] "v"(t_limit), [eps] "s"(eps)
 
 #define RT_ANY_HIT_CULL "v_cmpx_ngt_f32 vcc, %[eps], %[d]\n"                                         /* !(d < eps) */
 #define RT_ANY_HIT_NOCULL "v_and_b32 %[t0], 0x7fffffff, %[d]\n v_cmpx_ngt_f32 vcc, %[eps], %[t0]\n" /* !(|d| < eps) */
 // One asm statement: save EXEC, select the lanes (PROLOGUE), run the stages, restore EXEC.
-#define RT_ANY_HIT_ASM(PROLOGUE, FIRST_STAGE, EXTRA_INPUTS)                                     \
+#define RT_ANY_HIT_ASM(PROLOGUE, FIRST_STAGE, REC, EXTRA_INPUTS)                                \
     asm volatile("s_mov_b64 %[save], exec\n" PROLOGUE RT_ANY_HIT_STAGES(FIRST_STAGE)            \
                  : RT_ANY_HIT_OUTPUTS                                                            \
-                 : RT_ANY_HIT_INPUTS EXTRA_INPUTS                                                \
+                 : RT_ANY_HIT_INPUTS(REC) EXTRA_INPUTS                                           \
                  : "vcc", "scc")
 #define RT_ANY_HIT_MASKED_PROLOGUE                \
     "s_andn2_b64 exec, %[need], %[found]\n"       \
@@ -210,10 +214,24 @@ __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax
     float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
     lanemask save;
     const float eps = kEps;
-    if constexpr (MASKED && CULL) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_CULL, RT_ANY_HIT_MASKED_INPUTS);
-    else if constexpr (MASKED) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_NOCULL, RT_ANY_HIT_MASKED_INPUTS);
-    else if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, );
-    else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, );
+    if constexpr (MASKED && CULL) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_CULL, "s", RT_ANY_HIT_MASKED_INPUTS);
+    else if constexpr (MASKED) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_NOCULL, "s", RT_ANY_HIT_MASKED_INPUTS);
+    else if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, "s", );
+    else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, "s", );
+}
+
+// The same test for one (ray, triangle) pair per lane: every lane brings its own ray, triangle and limit in vector
+// registers (the pair phases of the per-lane and task-pool forms).  Returns the lanes of `need` whose pair is an
+// occluder.  Same caller's guarantee as above.
+template <bool CULL>
+__device__ __forceinline__ lanemask any_hit_exec_pairs(lanemask need, f3 o, f3 s, f3 a, f3 e1, f3 e2, float t_limit) {
+    float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
+    lanemask save, found = 0;
+    const float eps = kEps;
+    const float ax = a.x, ay = a.y, az = a.z, e1x = e1.x, e1y = e1.y, e1z = e1.z, e2x = e2.x, e2y = e2.y, e2z = e2.z;
+    if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, "v", );
+    else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, "v", );
+    return found;
 }
 
 // Slab test exactly as src/collision_detection.h:71-86 with the per-ray reciprocals hoisted (the

@@ -120,7 +120,8 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
 }
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  `stk` is the wave's LDS stack.
-template <bool ANY, bool CULL>
+// FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& stk, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
@@ -234,11 +235,15 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                     if (p - o_excl >= first_n) slot = o_slot2 + (p - o_excl - first_n);
                 }
                 const bool on = pair && !((decided >> L) & 1ull);
-                const float4* r = reinterpret_cast<const float4*>(T.slots + (on ? slot : 0u));
-                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
+                const f3 a = mk(g[0], g[1], g[2]), e1 = mk(g[3], g[4], g[5]), e2 = mk(g[6], g[7], g[8]);
                 float t = RT_INF;
-                const lanemask hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                lanemask hit;
+                if constexpr (ANY && FAST && kHandScheduledTests) {
+                    hit = any_hit_exec_pairs<CULL>(ballot64(on), ro, rd, a, e1, e2, __shfl(t_limit, (int)L, 64));  // renderer.cc:302 included
+                } else {
+                    hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                }
                 if (hit == 0) continue;
                 // this lane's leaf covers positions [lo, hi) of the chunk
                 const bool here = cnt != 0 && excl < base + 64 && incl > base;
@@ -247,25 +252,23 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                 const lanemask below_hi = hi >= 64u ? ~0ull : ((1ull << hi) - 1ull);
                 const lanemask range = here ? (below_hi & ~((1ull << lo) - 1ull)) : 0ull;
                 if (ANY) {
-                    const float rlim = __shfl(t_limit, (int)L, 64);
-                    const lanemask good = hit & ballot64(t < rlim);  // renderer.cc:302
+                    lanemask good = hit;
+                    if constexpr (!(FAST && kHandScheduledTests)) good = hit & ballot64(t < __shfl(t_limit, (int)L, 64));  // renderer.cc:302
                     const bool f = (good & range) != 0;
                     found = found || f;
                     decided |= ballot64(f);
                 } else {
-                    const uint32_t tri = __float_as_uint(r2.y);
                     lanemask m = hit & range;
                     while (ballot64(m != 0) != 0) {
                         const bool has = m != 0;
                         const uint32_t c = has ? (uint32_t)__builtin_ctzll(m) : lane;
                         m &= m - 1ull;
                         const float tc = __shfl(t, (int)c, 64);
-                        const uint32_t sc = __shfl(slot, (int)c, 64), trc = __shfl(tri, (int)c, 64);
+                        const uint32_t sc = __shfl(slot, (int)c, 64);
                         // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
                         const bool b = has && (tc < h.t || (tc == h.t && sc < h.slot));
                         h.t = b ? tc : h.t;
                         h.slot = b ? sc : h.slot;
-                        h.tri = b ? trc : h.tri;
                     }
                 }
             }
@@ -279,6 +282,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
         }
     }
     if (ANY) h.found = ballot64(found);
+    else if (h.slot != 0xffffffffu) h.tri = T.slots[h.slot].tri;  // the winner's triangle index, read once
 #ifdef RT_LANE_PROFILE
     RT_PROF_ADD(0, pa); RT_PROF_ADD(1, pb); RT_PROF_ADD(2, psteps); RT_PROF_ADD(3, plan); RT_PROF_ADD(4, pch); RT_PROF_ADD(5, ppairs); RT_PROF_ADD(6, 1); RT_PROF_ADD(7, prounds);
 #endif

@@ -58,7 +58,8 @@ struct PoolLds {  // of one wave
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  The root must be an internal node
 // and leaves must hold fewer than 2^26 triangles (the host selects this form only then).
-template <bool ANY, bool CULL>
+// FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
+template <bool ANY, bool CULL, bool FAST = false>
 __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
@@ -120,15 +121,19 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
                 const f3 rd = mk(__shfl(d.x, (int)ray, 64), __shfl(d.y, (int)ray, 64), __shfl(d.z, (int)ray, 64));
                 const uint32_t slot = o_slot + (p - o_excl);
                 const bool on = pair && !(ANY && ((decided >> ray) & 1ull));
-                const float4* r = reinterpret_cast<const float4*>(T.slots + (on ? slot : 0u));
-                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
+                const f3 a = mk(g[0], g[1], g[2]), e1 = mk(g[3], g[4], g[5]), e2 = mk(g[6], g[7], g[8]);
                 float t = RT_INF;
-                const lanemask hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                lanemask hit;
+                if constexpr (ANY && FAST && kHandScheduledTests) {
+                    hit = any_hit_exec_pairs<CULL>(ballot64(on), ro, rd, a, e1, e2, __shfl(t_limit, (int)ray, 64));  // renderer.cc:302 included
+                } else {
+                    hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                }
                 if (hit == 0) continue;
                 if (ANY) {
-                    const float rlim = __shfl(t_limit, (int)ray, 64);
-                    lanemask good = hit & ballot64(t < rlim);  // renderer.cc:302
+                    lanemask good = hit;
+                    if constexpr (!(FAST && kHandScheduledTests)) good = hit & ballot64(t < __shfl(t_limit, (int)ray, 64));  // renderer.cc:302
                     while (good != 0) {
                         const int g = __builtin_ctzll(good);
                         good &= good - 1ull;
