@@ -302,19 +302,30 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     gathers = [rd.BandGather(H, W, rank, world, "cuda", dist) for _ in range(2)]
     overlap = dist is not None and os.environ.get("RT_BENCH_SYNC_GATHER") != "1"
+    # The gathers run on a worker thread with its own stream (RT_BENCH_GATHER_THREAD=0: on this thread, between the
+    # frames): the renderer's call only returns when its frame is complete, so whatever this thread does between two
+    # calls -- the host side of the collective included -- would otherwise add to every frame.
+    worker = rd.GatherThread(frames, gathers) if overlap and os.environ.get("RT_BENCH_GATHER_THREAD") != "0" else None
     step_no = [0]
 
     def step():
         k = step_no[0] & 1
         step_no[0] += 1
-        gathers[k].finish()  # this buffer's previous frame must have arrived before it is overwritten
+        if worker is not None:
+            worker.wait(k)  # this buffer's previous frame must have arrived before it is overwritten
+            _, st = ads.render(cfg, out_ptr=frames[k].data_ptr(), stream=stream)
+            worker.submit(k)  # framebuffer bands -> rank 0
+            return st
+        gathers[k].finish()
         _, st = ads.render(cfg, out_ptr=frames[k].data_ptr(), stream=stream)
-        gathers[k].start(frames[k])  # framebuffer bands -> rank 0; no-op for one rank
+        gathers[k].start(frames[k])  # no-op for one rank
         if not overlap:
             gathers[k].finish()
         return st
 
     def fence():
+        if worker is not None:
+            worker.wait()
         for g_ in gathers:
             g_.finish()
         torch.cuda.synchronize()
@@ -331,6 +342,8 @@ def main():
         add_stats(acc, step())
     fence()
     elapsed = time.perf_counter() - t0
+    if worker is not None:
+        worker.close()
     rays = acc["rays"]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -5,6 +5,9 @@ b % world; the scene is replicated; nothing is exchanged while rendering.  After
 its bands inside a full-size frame buffer; `gather_bands` moves them to rank 0 with one collective
 (`torch.distributed.gather`: RCCL on GPUs, gloo on CPU) and interleaves them back into rank 0's frame.
 """
+import queue
+import threading
+
 import torch
 
 BAND_ROWS = 8
@@ -86,3 +89,53 @@ class BandGather:
         self.start(frame)
         self.finish()
         return frame
+
+
+class GatherThread:
+    """Runs the gathers of a ring of (frame buffer, BandGather) pairs on a worker thread with its own stream, so that
+    neither the host side of the collective (tens of microseconds per call) nor its copies sit between two frames of
+    the rendering thread.  submit(k) hands over buffer k, whose frame must be complete (the renderer's call has
+    returned); wait(k) returns once that gather is complete and the buffer may be overwritten.  All collectives of the
+    process group are issued by this one thread, in submission order -- the same order on every rank."""
+
+    def __init__(self, frames, gathers, device="cuda"):
+        self.frames, self.gathers = frames, gathers
+        self.done = [threading.Event() for _ in frames]
+        for e in self.done:
+            e.set()
+        self.error = None
+        self.jobs = queue.Queue()
+        self.stream = torch.cuda.Stream(device=device) if torch.cuda.is_available() and str(device).startswith("cuda") else None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            k = self.jobs.get()
+            if k is None:
+                return
+            try:
+                if self.stream is not None:
+                    with torch.cuda.stream(self.stream):
+                        self.gathers[k](self.frames[k])
+                    self.stream.synchronize()
+                else:
+                    self.gathers[k](self.frames[k])
+            except BaseException as e:  # reported by the next wait()
+                self.error = e
+            self.done[k].set()
+
+    def submit(self, k):
+        self.done[k].clear()
+        self.jobs.put(k)
+
+    def wait(self, k=None):
+        for e in (self.done if k is None else [self.done[k]]):
+            e.wait()
+        if self.error is not None:
+            raise self.error
+
+    def close(self):
+        self.wait()
+        self.jobs.put(None)
+        self.thread.join()

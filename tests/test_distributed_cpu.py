@@ -99,6 +99,47 @@ def test_pipelined_gather(world, tmp_path):
         assert np.array_equal(got[k], want), k
 
 
+def _thread_worker(rank, world, port, out_path):
+    """The same frame loop with the gathers on rd.GatherThread, as bench.py runs it by default."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = [rd.alloc_frame(H, W, world, "cpu") for _ in range(2)]
+        gathers = [rd.BandGather(H, W, rank, world, "cpu", dist) for _ in range(2)]
+        worker = rd.GatherThread(frames, gathers, device="cpu")
+        rows = rd.rows_of_rank(H, rank, world)
+        seen = []
+        n_frames = 6
+        for k in range(n_frames + 2):
+            b = k & 1
+            worker.wait(b)
+            if rank == 0 and k >= 2:
+                seen.append(frames[b][:H].clone().numpy())  # frame k - 2 has arrived
+            if k < n_frames:
+                frames[b].zero_()
+                for r in rows:
+                    frames[b][r] = float(1000 * k + r)
+                worker.submit(b)
+        worker.close()
+        if rank == 0:
+            np.save(out_path, np.stack(seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_thread(world, tmp_path):
+    out = str(tmp_path / "thread.npy")
+    mp.spawn(_thread_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape[0] == 6
+    for k in range(6):
+        want = (1000 * k + np.arange(H, dtype=np.float32))[:, None, None] * np.ones((1, W, 3), np.float32)
+        assert np.array_equal(got[k], want), k
+
+
 def test_band_bookkeeping():
     for h in (1, 7, 8, 9, 1080, 2160):
         for world in (1, 2, 3, 8):
