@@ -110,6 +110,8 @@ class GatherThread:
         self.thread.start()
 
     def _run(self):
+        if self.stream is not None:
+            torch.cuda.set_device(self.stream.device)  # a new thread starts on device 0
         while True:
             k = self.jobs.get()
             if k is None:
