@@ -142,6 +142,16 @@ def test_clustered_layout(scenes, scene, mb, md):
     assert used.all() and repeats > 0
 
 
+def test_clustered_form_does_not_apply(scenes):
+    """A root leaf has nothing to cluster, and a tree in which no cluster lists a triangle twice gains nothing."""
+    sc = scenes["original"]
+    assert HostTree(sc.pos, 1000000, 10).export_clustered() is None  # the root is a leaf
+    # two far-apart triangles, one per leaf: no triangle is listed by two leaves of a cluster
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[100, 100, 100], [101, 100, 100], [100, 101, 100]]], np.float32)
+    ht = HostTree(tri, 1, 4)
+    assert ht.n_records >= 1 and ht.export_clustered() is None
+
+
 def test_synthetic_tree_equals_oracle_and_reference(orc):
     """Icosphere-in-Cornell-box scene: level 5 (20,514 triangles) node-for-node against the oracle; level 8
     (1,310,754 triangles) against the tree shape the reference binary printed (tests/golden/ref_kats.json S8)."""
