@@ -27,7 +27,7 @@
 #define RT_CLOSEST_OCCUPANCY(MODE)
 #endif
 #if RT_SHADOW_WAVES
-#define RT_SHADOW_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu((MODE) == 0 ? RT_SHADOW_WAVES : 4, 8)))
+#define RT_SHADOW_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu(((MODE) == 0 || (MODE) == 3) ? RT_SHADOW_WAVES : 4, 8)))
 #else
 #define RT_SHADOW_OCCUPANCY(MODE)
 #endif
