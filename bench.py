@@ -159,14 +159,24 @@ def add_stats(acc, st):
     acc["closest_rays"] += st.timed_closest_rays
 
 
-def pmc_summary():
-    """The committed counter summary of the latest round (tools/pmc_profile.sh), or {}."""
+def pmc_file():
+    """The counter summary to quote: the committed one of the latest round, or the file RT_BENCH_COUNTERS names (a
+    summary just collected on this box, tools/refresh_round.sh)."""
     import glob
+    override = os.environ.get("RT_BENCH_COUNTERS")
+    if override and os.path.exists(override):
+        return override, "profiles/" + os.path.basename(override)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
-    if not files:
+    return (files[-1], "profiles/" + os.path.basename(files[-1])) if files else (None, None)
+
+
+def pmc_summary():
+    """The per-workload counters of pmc_file() (tools/pmc_profile.sh), or {}."""
+    path, src = pmc_file()
+    if not path:
         return {}, None
-    with open(files[-1]) as f:
-        return json.load(f).get("workloads", {}), "profiles/" + os.path.basename(files[-1])
+    with open(path) as f:
+        return json.load(f).get("workloads", {}), src
 
 
 def memory_side(kernels, name, workload):
@@ -462,14 +472,12 @@ def main():
                 "other_kernels": {"k_closest": ks["k_closest"], "k_shade": ks["k_shade"]}}
         # Counter evidence comes from separate rocprofv3 --pmc passes of this same command (tools/pmc_profile.sh); they
         # cannot be collected from inside the run, so the committed summary of the latest round is quoted.
-        import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
-        if pmc_files and world == 1:
-            with open(pmc_files[-1]) as f:
+        pmc_path, src = pmc_file()
+        if pmc_path and world == 1:
+            with open(pmc_path) as f:
                 pmc = json.load(f)
             k = pmc.get("workloads", {}).get(args.workload, {}).get("kernels", {}).get("k_shadow")
             if k:
-                src = f"profiles/{os.path.basename(pmc_files[-1])}"
                 if "bytes_per_launch" in k:
                     roof["traffic"] = k["bytes_per_launch"]
                     roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, reads doubled per the gfx950 rule; bytes per launch)"

@@ -6,7 +6,7 @@ set -e
 cd "${GRAFT_REPO_ROOT:-.}"
 timeout -k 10 900 bash tools/pmc_profile.sh r02 > gpurun_out/pmc_profile.log 2>&1
 echo pmc done
-timeout -k 10 300 python3 bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+RT_BENCH_COUNTERS=gpurun_out/profiles_new/r02_pmc_counters.json timeout -k 10 300 python3 bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 echo bench done
 : > gpurun_out/band_times.txt
 for w in cornell_original_blinn_spt16_1080p synthetic_ico8_phong_4k cornell_sphere_blinn_smooth_spp4_1080p; do
