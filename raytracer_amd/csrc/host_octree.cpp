@@ -260,6 +260,7 @@ bool flatten_octree(const HostOctree& t, const float* positions, FlatOctree& out
             }
             r.nonempty |= 1u << o;
         }
+        node_ordered_nonempty(r.nonempty, &r.pad[1]);
     }
     // small-tree form
     {

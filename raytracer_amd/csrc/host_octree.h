@@ -66,6 +66,9 @@ constexpr uint32_t kClusterMaxLeaves = 32, kClusterOrdShift = 24, kClusterSlotMa
 // info[o][1] == 0: octant o is null/empty (skipped before any box test, octree.cc:195);
 // info[o][1] & kChildInternal: internal child whose NodeRec index is info[o][0]; otherwise a leaf with info[o][1]
 // triangles whose slots start at info[o][0].
+// pad[1..2] of a record of the plain tree: `nonempty` in the octant order of each of the 8 sign patterns a ray direction
+// can have (byte f of the 64 bits pad[1] | pad[2] << 32: bit k = bit (k ^ f) of nonempty, see node_ordered_nonempty);
+// the per-lane walks read the byte of their ray.  The clustered form's copy of the records uses pad[0..1] for its lists.
 struct alignas(128) NodeRec {
     float lo[3][2];     // [axis][bit]: min plane of the octants whose axis bit is 0 / 1
     float hi[3][2];     // [axis][bit]: max plane
@@ -74,6 +77,18 @@ struct alignas(128) NodeRec {
     uint32_t info[8][2];
 };
 static_assert(sizeof(NodeRec) == 128, "NodeRec must be 128 bytes");
+
+// A ray that runs backwards along an axis (1 / dir < 0) meets the octants with that axis bit set first.  With
+// flip = (x backwards) << 2 | (y backwards) << 1 | (z backwards), the octants in the order k = 0..7 -> octant k ^ flip
+// are front to back for the ray.  word 0: the masks for flip 0..3 (one byte each), word 1: for flip 4..7.
+RT_HD void node_ordered_nonempty(uint32_t nonempty, uint32_t out[2]) {
+    out[0] = out[1] = 0;
+    for (uint32_t f = 0; f < 8; ++f) {
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < 8; ++k) m |= ((nonempty >> (k ^ f)) & 1u) << k;
+        out[f >> 2] |= m << ((f & 3u) * 8u);
+    }
+}
 
 struct FlatOctree {
     std::vector<NodeRec> nodes;  // internal nodes, breadth-first

@@ -317,7 +317,8 @@ __global__ void __launch_bounds__(256) k_build_emit(const BuildNode* __restrict_
             r.hi[ax][b] = used ? comp(cmax, ax) : 0.0f;
         }
     r.nonempty = nonempty;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    r.pad[0] = 0;
+    node_ordered_nonempty(nonempty, &r.pad[1]);
     for (int o = 0; o < 8; ++o) r.info[o][0] = r.info[o][1] = 0;  // the children fill theirs in the next depth's pass
     recs[rec] = r;
     uint32_t ci = pk[CH_CHILDREN], cl = pk[CH_CHILD_LIST];

@@ -118,29 +118,31 @@ struct SearchWork {
 
 constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
+constexpr bool kClipDefault = false;
 constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots are walked by the wave together, whatever the rays
 
 // Launches KERNEL<cull, mode>(args...) for run-time cull / traversal mode.
-#define RT_LAUNCH_MODE(KERNEL, CULL, mode, grid, block, stream, ...)                                                \
+// lds: bytes of dynamic LDS (the per-lane form's stacks; 0 for the others).
+#define RT_LAUNCH_MODE(KERNEL, CULL, mode, grid, block, lds, stream, ...)                                           \
     do {                                                                                                            \
         if ((mode) == MODE_POOL) hipLaunchKernelGGL((KERNEL<CULL, MODE_POOL>), grid, block, 0, stream, __VA_ARGS__);          \
-        else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<CULL, MODE_LANE>), grid, block, 0, stream, __VA_ARGS__);     \
+        else if ((mode) == MODE_LANE) hipLaunchKernelGGL((KERNEL<CULL, MODE_LANE>), grid, block, lds, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL((KERNEL<CULL, MODE_WAVE>), grid, block, 0, stream, __VA_ARGS__);                    \
     } while (0)
-#define RT_LAUNCH2(KERNEL, cull, mode, grid, block, stream, ...)                                                    \
+#define RT_LAUNCH2(KERNEL, cull, mode, grid, block, lds, stream, ...)                                               \
     do {                                                                                                            \
-        if (cull) RT_LAUNCH_MODE(KERNEL, true, mode, grid, block, stream, __VA_ARGS__);                             \
-        else RT_LAUNCH_MODE(KERNEL, false, mode, grid, block, stream, __VA_ARGS__);                                 \
+        if (cull) RT_LAUNCH_MODE(KERNEL, true, mode, grid, block, lds, stream, __VA_ARGS__);                        \
+        else RT_LAUNCH_MODE(KERNEL, false, mode, grid, block, lds, stream, __VA_ARGS__);                            \
     } while (0)
 
 template <class... Args>
-void launch_shadow(bool cull, int mode, bool fast_tri, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+void launch_shadow(bool cull, int mode, bool fast_tri, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
 #define RT_SHADOW_CASE(MODE, WAVES)                                                                                          \
     if (mode == MODE) {                                                                                                      \
-        if (fast_tri && cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, true>), grid, block, 0, stream, args...);       \
-        else if (fast_tri) hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, true>), grid, block, 0, stream, args...);         \
-        else if (cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, false>), grid, block, 0, stream, args...);             \
-        else hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, false>), grid, block, 0, stream, args...);                      \
+        if (fast_tri && cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, true>), grid, block, lds, stream, args...);     \
+        else if (fast_tri) hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, true>), grid, block, lds, stream, args...);       \
+        else if (cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, false>), grid, block, lds, stream, args...);           \
+        else hipLaunchKernelGGL((k_shadow<false, MODE, WAVES, false>), grid, block, lds, stream, args...);                    \
         return;                                                                                                              \
     }
     RT_SHADOW_CASE(MODE_POOL, 1)   // one-wave blocks
@@ -186,6 +188,8 @@ struct rt_ads {
     uint32_t max_per_bb = 16, max_depth = 10;
     bool built = false, shading_set = false, has_normals = false, branching = false, branching_any = false, use_flat = true;
     int traversal = 0;  // 0 = choose per launch, 1 = always wave-together, 2 = always per-lane, 3 = always the task pool
+    // walk only the part of a ray that can contribute a result (Span in rt_traverse.h); false: the reference's whole line
+    bool clip = false;
     uint32_t pool_target_waves = 8192, pool_min_rays = 1;
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
@@ -271,7 +275,12 @@ int traversal_mode(const rt_ads* a, bool coherent_primary, bool any_hit, uint64_
     const bool pool_ok = a->shape.max_tris_in_leaf < (1u << kPoolCountBits);
     if (a->traversal == 2) return MODE_LANE;
     if (a->traversal == 3) return pool_ok ? MODE_POOL : MODE_LANE;
-    if (small_tree || a->n_slots < kWaveFormMaxSlots || coherent_primary) return wave;
+    if (small_tree || a->n_slots < kWaveFormMaxSlots) return wave;
+    // Clipped walks are short (an ordered closest-hit walk ends soon after its first hit, an any-hit walk covers the
+    // segment only), and the per-lane form then beats both the union walk of a tile of camera rays (1.31 M triangles, 4K:
+    // 1.04 against 1.79 ms) and the task pool for small launches (88 K rays: 31 against 104 us).
+    if (a->clip) return MODE_LANE;
+    if (coherent_primary) return wave;
     return (pool_ok && n_rays < (any_hit ? kPoolMaxRaysAny : kPoolMaxRaysClosest)) ? MODE_POOL : MODE_LANE;
 }
 
@@ -290,14 +299,14 @@ uint32_t pool_sparse(const rt_ads* a, int mode, uint64_t n_rays, uint32_t max_gr
 uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE && a->n_slots < kWaveFormMaxSlots) ? 1024u : 256u; }
 
 template <class... Args>
-void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+void launch_closest(bool cull, int mode, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
     const bool big = block.x > 256;
     if (mode == MODE_POOL) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_POOL, false>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_POOL, false>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {
-        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_LANE, false>), grid, block, 0, stream, args...);
-        else hipLaunchKernelGGL((k_closest<false, MODE_LANE, false>), grid, block, 0, stream, args...);
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_LANE, false>), grid, block, lds, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_LANE, false>), grid, block, lds, stream, args...);
     } else if (big) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_WAVE, true>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_WAVE, true>), grid, block, 0, stream, args...);
@@ -311,6 +320,14 @@ void launch_closest(bool cull, int mode, dim3 grid, dim3 block, hipStream_t stre
 uint64_t mode_threads(int, uint64_t n_rays, uint32_t sparse = 0) {
     const uint64_t per_wave = 64u >> sparse;
     return (n_rays + per_wave - 1) / per_wave * 64u;
+}
+
+// Levels of internal nodes of the resident tree (the depth of the per-lane stacks), the packed launch options of a
+// traversal kernel, and the dynamic LDS a launch of the per-lane form needs.
+uint32_t tree_levels(const rt_ads* a) { return std::max<uint32_t>(a->max_stack / 8u, 1u); }
+uint32_t launch_opts(const rt_ads* a, uint32_t sparse) { return trace_opts(sparse, a->clip, tree_levels(a)); }
+size_t lane_lds(const rt_ads* a, int mode, uint32_t block_threads, bool closest) {
+    return mode == MODE_LANE ? (size_t)(block_threads / 64u) * lane_stack_words(tree_levels(a), closest) * sizeof(uint32_t) : 0;
 }
 
 int use_device(const rt_ads* a) {
@@ -869,6 +886,8 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     }
     a->use_clusters = true;
     if (const char* e = getenv("RT_DISABLE_CLUSTERS")) a->use_clusters = !(e[0] == '1');
+    a->clip = kClipDefault;
+    if (const char* e = getenv("RT_CLIP")) a->clip = e[0] == '1';
     if (int rc = make_cluster_form(a)) return rc;
     // the slots' geometry alone, for the forms that read it per lane
     HIP_TRY(a->d_slot_geom.reserve((size_t)std::max<uint64_t>(a->n_slots, 1) * 9));
@@ -1119,7 +1138,8 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
     const int mode = traversal_mode(a, false, false, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
-    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, sparse);
+    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, lane_lds(a, mode, block.x, true), stream, dev_tree(a), d_o, d_d, n, d_t, d_tri,
+               launch_opts(a, sparse));
     HIP_TRY(hipGetLastError());
     if (a->collect_stats) {
         if (int rc = stats_begin(a, stream)) return rc;
@@ -1162,21 +1182,22 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     }
     const int mode = traversal_mode(a, false, true, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
+    const uint32_t opts = launch_opts(a, sparse);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
     if (mode == MODE_CLUSTER || (mode == MODE_WAVE && a->fast_tri)) {
         const DevOctree T = dev_tree(a);
         if (mode == MODE_CLUSTER && a->fast_tri) {
-            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
-            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
         } else if (mode == MODE_CLUSTER) {
-            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
-            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_CLUSTER>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
         } else {
-            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
-            else hipLaunchKernelGGL((k_trace_any<false, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, sparse);
+            if (cull) hipLaunchKernelGGL((k_trace_any<true, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
+            else hipLaunchKernelGGL((k_trace_any<false, MODE_WAVE, true>), grid, block, 0, stream, T, d_p, d_l, n, d_out, opts);
         }
     } else {
-        RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, stream, dev_tree(a), d_p, d_l, n, d_out, sparse);
+        RT_LAUNCH2(k_trace_any, cull != 0, mode, grid, block, lane_lds(a, mode, block.x, false), stream, dev_tree(a), d_p, d_l, n, d_out, opts);
     }
     HIP_TRY(hipGetLastError());
     if (a->collect_stats) {
@@ -1473,8 +1494,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, cap, sparse_c) + block_c.x - 1) / block_c.x));
             if (int rc = mark(CLS_CLOSEST)) return rc;
             const bool timed_c = last_timed;
-            launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p, lv.out.p,
-                       lv.work.p, cnt, sparse_c);
+            launch_closest(F.cull != 0, mode_c, grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, S, F, L, lv.rays.p, cap, lv.hit_t.p,
+                           lv.hit_tri.p, lv.out.p, lv.work.p, cnt, launch_opts(a, sparse_c));
             HIP_TRY(hipGetLastError());
             st.launches_closest++;
             if (a->collect_stats) {
@@ -1508,8 +1529,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
                 const dim3 block_a(wave_a ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
-                launch_shadow(F.cull != 0, mode_a, a->fast_tri, grid_a, block_a, stream, S, F, L, lv.rays.p, cap, lv.hit_t.p, lv.hit_tri.p,
-                           lv.work.p, lv.vis.p, words, pshift, gshift, cnt, sparse_a);
+                launch_shadow(F.cull != 0, mode_a, a->fast_tri, grid_a, block_a, lane_lds(a, mode_a, block_a.x, false), stream, S, F, L, lv.rays.p, cap,
+                              lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words, pshift, gshift, cnt, launch_opts(a, sparse_a));
                 HIP_TRY(hipGetLastError());
                 st.launches_shadow++;
                 if (a->collect_stats) {
@@ -1645,8 +1666,8 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     const int mode_c = traversal_mode(a, true, false, n0);
     const uint32_t sparse_c = pool_sparse(a, mode_c, n0, 1);
     const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0, sparse_c) + block_c.x - 1) / block_c.x));
-    launch_closest(F.cull != 0, mode_c, grid_c, block_c, stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0, lv.hit_t.p,
-               lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p, sparse_c);
+    launch_closest(F.cull != 0, mode_c, grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0,
+                   lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p, launch_opts(a, sparse_c));
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());
@@ -1672,16 +1693,15 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
 }  // extern "C"
 
 #ifdef RT_LANE_PROFILE
-extern "C" int rt_debug_lane_profile(unsigned long long* out32) {  // 48 values
-    if (hipMemcpyFromSymbol(out32 + 32, HIP_SYMBOL(rt::g_pool_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pool_prof), z, sizeof z) != hipSuccess) return 1;
-    }
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    unsigned long long z[16] = {0};
-    if (hipMemcpyFromSymbol(out32 + 16, HIP_SYMBOL(rt::g_wave_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wave_prof), z, sizeof z) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof z) != hipSuccess;
+// 64 values: [0,32) per-lane form (closest, any-hit: 16 each), [32,48) wave-together forms, [48,64) task pool (closest, any-hit: 8 each);
+// the counters are cleared.
+extern "C" int rt_debug_lane_profile(unsigned long long* out64) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rt::g_lane_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out64 + 32, HIP_SYMBOL(rt::g_wave_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out64 + 48, HIP_SYMBOL(rt::g_pool_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_prof), z, sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wave_prof), z, sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pool_prof), z, sizeof(unsigned long long) * 16) != hipSuccess;
 }
 #endif

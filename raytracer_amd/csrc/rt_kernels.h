@@ -56,13 +56,19 @@ struct TraverseLds {
     uint32_t unused;
 };
 template <>
-struct TraverseLds<MODE_LANE> {
-    LaneStackLds s;
-};
-template <>
 struct TraverseLds<MODE_POOL> {
     PoolLds s;
 };
+// The per-lane form keeps its stacks in dynamic LDS, sized at launch for the tree's depth (lane_stack_words).
+extern __shared__ uint32_t rt_dyn_lds[];
+
+// Launch options of the traversal kernels, packed into one kernel argument (the wave-together forms sit at the edge of
+// their scalar register budget): bits 0..3 `sparse` (see ray_index), bit 4 `clip` (walk only the part of a ray that can
+// contribute a result, see Span), bits 8..15 the tree's levels of internal nodes (depth of the per-lane stacks).
+__host__ __device__ constexpr uint32_t trace_opts(uint32_t sparse, bool clip, uint32_t levels) { return sparse | (clip ? 16u : 0u) | (levels << 8); }
+__device__ __forceinline__ uint32_t opts_sparse(uint32_t opts) { return opts & 15u; }
+__device__ __forceinline__ bool opts_clip(uint32_t opts) { return (opts & 16u) != 0u; }
+__device__ __forceinline__ uint32_t opts_levels(uint32_t opts) { return (opts >> 8) & 0xffu; }
 // a, e1, e2 of every leaf slot as 9 consecutive floats (DevOctree::slot_geom).
 __global__ void __launch_bounds__(256) k_pack_slot_geometry(const LeafTri* __restrict__ slots, uint32_t n, float* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,13 +90,20 @@ __device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool&
 }
 // FAST: any-hit rays with unit-length directions in a scene within the bound of any_hit_exec.
 template <bool ANY, bool CULL, int MODE, bool FAST = false>
-__device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    if constexpr (MODE == MODE_LANE) traverse_lane<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, h);
-    else if constexpr (MODE == MODE_POOL) traverse_pool<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, h);
-    else if constexpr (MODE == MODE_CLUSTER) {
+__device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, uint32_t opts, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+    const bool clip = opts_clip(opts);
+    if constexpr (MODE == MODE_LANE) {
+        const uint32_t levels = opts_levels(opts);
+        const LaneStack stk = lane_stack(rt_dyn_lds + (threadIdx.x >> 6) * lane_stack_words(levels, !ANY), levels);
+        traverse_lane<ANY, CULL, ANY && FAST>(T, stk, valid, o, d, t_limit, clip, h);
+    } else if constexpr (MODE == MODE_POOL) {
+        traverse_pool<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, clip, h);
+    } else if constexpr (MODE == MODE_CLUSTER) {
         static_assert(ANY, "the clustered form serves any-hit queries");
-        traverse_any_clustered<CULL, FAST>(T, valid, o, d, t_limit, h);
-    } else traverse<ANY, CULL, FAST>(T, valid, o, d, t_limit, h);
+        traverse_any_clustered<CULL, FAST>(T, valid, o, d, t_limit, clip, h);
+    } else {
+        traverse<ANY, CULL, FAST>(T, valid, o, d, t_limit, clip, h);
+    }
 }
 
 struct alignas(16) TriShade {  // per triangle in Build order
@@ -303,9 +316,9 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counters, bool want, 
 
 template <bool CULL, int MODE>
 __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float* __restrict__ orig, const float* __restrict__ dir,
-                                                       uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri, uint32_t sparse) {
+                                                       uint64_t n, float* __restrict__ out_t, int32_t* __restrict__ out_tri, uint32_t opts) {
     bool lane_ok;
-    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, opts_sparse(opts), lane_ok);
     const bool valid = lane_ok && i < n;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     if (valid) {
@@ -314,7 +327,7 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
     }
     __shared__ TraverseLds<MODE> lds[4];
     HitState h;
-    trace<false, CULL, MODE>(T, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
+    trace<false, CULL, MODE>(T, lds[threadIdx.x >> 6], opts, valid, o, d, 0.0f, h);
     if (valid) {
         out_t[i] = h.t;
         out_tri[i] = (h.t == RT_INF) ? -1 : (int32_t)h.tri;  // renderer.cc:140
@@ -323,9 +336,9 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevOctree T, const float*
 
 template <bool CULL, int MODE, bool FAST = false>  // FAST: see trace<> (the directions are normalised here)
 __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __restrict__ point, const float* __restrict__ light,
-                                                   uint64_t n, uint8_t* __restrict__ out, uint32_t sparse) {
+                                                   uint64_t n, uint8_t* __restrict__ out, uint32_t opts) {
     bool lane_ok;
-    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t i = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, opts_sparse(opts), lane_ok);
     const bool valid = lane_ok && i < n;
     f3 p = mk(0, 0, 0), l = mk(0, 0, 1);
     if (valid) {
@@ -338,7 +351,7 @@ __global__ void __launch_bounds__(256) k_trace_any(DevOctree T, const float* __r
     const f3 d = normalize(pl);
     __shared__ TraverseLds<MODE> lds[4];
     HitState h;
-    trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], valid, p, d, dist, h);
+    trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], opts, valid, p, d, dist, h);
     if (valid) out[i] = lane_of(h.found) ? 1 : 0;
 }
 
@@ -396,19 +409,19 @@ __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __r
 template <bool CULL, int MODE, bool BIG>
 __global__ void __launch_bounds__(BIG ? 1024 : 256) RT_CLOSEST_OCCUPANCY(MODE) k_closest(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_tri, NodeOut* __restrict__ out,
-                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ counters, uint32_t sparse) {
+                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ counters, uint32_t opts) {
     // n: the rays of level 0; for deeper levels an upper bound, the number itself being the previous level's CNT_NEXT
     // (`counters` is the level's own block; the blocks of the levels are consecutive).  Threads beyond it carry no ray.
     if (level > 0) n = counters[CNT_NEXT - CNT_WORDS];
     bool lane_ok;
-    const uint32_t i = (uint32_t)ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint32_t i = (uint32_t)ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, opts_sparse(opts), lane_ok);
     bool valid;
     f3 o, d;
     uint32_t pixel, node_id;
     load_ray(F, rays, level, i, lane_ok ? n : 0u, valid, o, d, pixel, node_id);
     __shared__ TraverseLds<MODE> lds[BIG ? 16 : 4];
     HitState h;
-    trace<false, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], valid, o, d, 0.0f, h);
+    trace<false, CULL, MODE>(S.tree, lds[threadIdx.x >> 6], opts, valid, o, d, 0.0f, h);
     const bool hit = valid && !(h.t == RT_INF);
     if (valid) {
         hit_t[i] = h.t;
@@ -475,11 +488,11 @@ template <bool CULL, int MODE, int WAVES, bool FAST = false>
 __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
-                                                uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters, uint32_t sparse) {
+                                                uint32_t pshift, uint32_t gshift, uint32_t* __restrict__ counters, uint32_t opts) {
     __shared__ TraverseLds<MODE> lds[WAVES];
     const uint32_t group = 1u << gshift;  // sparse launches: group <= 64 >> sparse, so a group stays inside the lanes of a wave
     bool lane_ok;
-    const uint64_t ray_slot = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, sparse, lane_ok);
+    const uint64_t ray_slot = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, opts_sparse(opts), lane_ok);
     const uint32_t j = (uint32_t)(ray_slot >> gshift);
     const uint32_t sub = (uint32_t)ray_slot & (group - 1u);
     const uint32_t n_work = counters[CNT_WORK];
@@ -524,7 +537,7 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
         HitState h;
-        trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], on, P, d_l, dist, h);
+        trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
         const lanemask unshadowed = on_mask & ~h.found;
         const uint32_t word = smp >> 5;
         if (lit && writer && word < words)

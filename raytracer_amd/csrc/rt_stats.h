@@ -90,7 +90,8 @@ __device__ __forceinline__ void stats_walk(const DevOctree& T, f3 o, f3 d, f3 in
         return;
     }
     uint32_t rec = T.root_info0;
-    uint32_t pending = lane_node_pass(T.nodes, rec, o, inv);
+    const uint32_t flip = ray_flip(inv);  // (lane_node_pass numbers the octants in the ray's own order)
+    uint32_t pending = lane_node_pass<false>(T.nodes, rec, o, inv, flip, -RT_INF, RT_INF, nullptr);
     if (PASS == 0) c.slab += (uint32_t)__builtin_popcount(T.nodes[rec].nonempty);
     for (;;) {
         if (pending == 0) {
@@ -102,12 +103,12 @@ __device__ __forceinline__ void stats_walk(const DevOctree& T, f3 o, f3 d, f3 in
         }
         const uint32_t oct = (uint32_t)__builtin_ctz(pending);
         pending &= pending - 1u;
-        const uint32_t i0 = T.nodes[rec].info[oct][0], i1 = T.nodes[rec].info[oct][1];
+        const uint32_t i0 = T.nodes[rec].info[oct ^ flip][0], i1 = T.nodes[rec].info[oct ^ flip][1];
         if (PASS == 0) ++c.nodes;
         if (i1 & kChildInternal) {
             if (pending != 0 && sp < kLaneMaxLevels) stack[sp++] = (rec << 8) | pending;
             rec = i0;
-            pending = lane_node_pass(T.nodes, rec, o, inv);
+            pending = lane_node_pass<false>(T.nodes, rec, o, inv, flip, -RT_INF, RT_INF, nullptr);
             if (PASS == 0) c.slab += (uint32_t)__builtin_popcount(T.nodes[rec].nonempty);
         } else {
             leaf(i0, i1);

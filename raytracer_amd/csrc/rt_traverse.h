@@ -276,7 +276,39 @@ struct HitState {
     uint32_t slot;   // closest: global leaf slot of the winner (small-tree form: ordinal of its first reached leaf)
     uint32_t tri;    // closest: its triangle index
     lanemask found;  // any-hit: lanes that have found an occluder (wave-uniform)
+    lanemask tie;    // closest, pruned walk: lanes whose best distance was met by two distinct triangles (wave-uniform)
 };
+
+// ---- the part of a ray that is walked -----------------------------------------------------------------------------
+// The reference's slab test (collision_detection.h:71-86) starts its running bounds at -inf / +inf, so Octree::Search
+// returns the leaves along the whole LINE of the ray: behind its origin and, for a shadow ray, beyond the light.  The
+// loops over the candidates then discard what those leaves contribute: a hit needs t >= epsilon (renderer.cc:126,298),
+// a shadow hit t < distance to the light (:302), a closest hit t < the best so far (:130).  A triangle that is hit at
+// distance t contains the hit point, so it is listed by the leaf that contains that point (the triangle/box test of
+// Octree::Build assigns a triangle to every octant it touches, octree.cc:100-105), and every box on the way down to
+// that leaf contains the point too: their slab intervals contain t.  Starting the running bounds at [lo, hi] instead of
+// [-inf, +inf] therefore keeps every leaf that can contribute a hit with lo <= t <= hi, and the candidates it drops
+// could only have produced hits the loops discard.  The bounds are padded (kSpanPad of the length, plus kSpanPadAbs of
+// the origin's magnitude) far beyond the rounding of the slab products and of t itself; boxes overlap their neighbours by
+// 2e-6 of their coordinates on top (octree.cc:82-97).  Span{-inf, +inf} is the reference's walk.
+struct Span {
+    float lo, hi;
+};
+constexpr float kSpanPad = 0x1p-7f, kSpanPadAbs = 0x1p-10f;
+__device__ __forceinline__ Span span_all() { return Span{-RT_INF, RT_INF}; }
+__device__ __forceinline__ float span_pad_abs(f3 o) {
+    return (__builtin_fmaxf(__builtin_fmaxf(fabsf(o.x), fabsf(o.y)), __builtin_fmaxf(fabsf(o.z), 1.0f))) * kSpanPadAbs;
+}
+// Any-hit ray of length dist (renderer.cc:289-302): occluders lie in [epsilon, dist).  A ray whose length or origin is
+// not finite is walked like the reference walks it.
+__device__ __forceinline__ Span span_segment(f3 o, float dist, bool clip) {
+    const float pad = dist * kSpanPad + span_pad_abs(o);
+    const bool bounded = clip && pad < RT_INF;  // (false for a NaN or infinite length or origin as well)
+    return Span{bounded ? -pad : -RT_INF, bounded ? dist + pad : RT_INF};
+}
+// Closest-hit ray: hits lie in [epsilon, best so far]; the upper end follows the best distance during the walk.
+__device__ __forceinline__ float span_lo_closest(f3 o, bool clip) { return clip ? -span_pad_abs(o) : -RT_INF; }
+__device__ __forceinline__ float span_hi_closest(float best, float pad_abs) { return best + (best * kSpanPad + pad_abs); }
 
 // ---- wide scalar loads -------------------------------------------------------------------------------------------
 // Records are fetched in blocks of 16 dwords (s_load_dwordx16) so that a node visit or a group of 4 triangles
@@ -321,9 +353,13 @@ __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32
         h.found |= hit & ballot64(t < t_limit);  // renderer.cc:302
     } else {
         // renderer.cc:130: strictly smaller t wins; equal t keeps the earlier candidate, which is the smaller global slot.
-        const lanemask better = hit & (ballot64(t < h.t) | (ballot64(t == h.t) & ballot64(slot < h.slot)));
-        if (better == 0) return;
+        const lanemask less = hit & ballot64(t < h.t), same_t = hit & ballot64(t == h.t);
+        const lanemask better = less | (same_t & ballot64(slot < h.slot));
         const uint32_t tri = RT_W(blk, 12 * j + 9);
+        // Two distinct triangles at the best distance: which one the reference takes depends on every leaf that lists
+        // them, also on leaves a pruned walk leaves out -- such rays are walked again without pruning (traverse<>).
+        h.tie = (h.tie & ~less) | (same_t & ballot64(tri != h.tri));
+        if (better == 0) return;
         const bool b = lane_of(better);
         h.t = b ? t : h.t;
         h.slot = b ? slot : h.slot;
@@ -505,10 +541,10 @@ __device__ __forceinline__ void slab_sides(const u32x16& pl, f3 o, f3 inv, SlabS
     }
 }
 // collision_detection.h:72-85 for octant c in its order: x, then y, then z, folded into the running max / min from
-// -inf / +inf.
-__device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c) {
+// -inf / +inf (the reference), or from the bounds of the part of the ray that is walked (Span).
+__device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c, float lo = -RT_INF, float hi = RT_INF) {
     const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-    float t_min = slab_max(-RT_INF, s.tn[0][bx]), t_max = slab_min(RT_INF, s.tf[0][bx]);
+    float t_min = slab_max(lo, s.tn[0][bx]), t_max = slab_min(hi, s.tf[0][bx]);
     t_min = slab_max(t_min, s.tn[1][by]);
     t_max = slab_min(t_max, s.tf[1][by]);
     t_min = slab_max(t_min, s.tn[2][bz]);
@@ -517,9 +553,11 @@ __device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c) {
 }
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
+// sp: the part of the ray whose boxes are walked.  prune (closest hit): the upper bound follows the best distance.
 template <bool ANY, bool CULL, bool FLAT, bool FAST = false>
-__device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
+__device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, Span sp, bool prune, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
+    const float pad_abs = span_pad_abs(o);
     WaveStack st;
     uint32_t reach = 0;
     cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);
@@ -535,11 +573,12 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
             const u32x16 info = sload16(rec + 16);  // dwords 16..31 = info[8][2]
             SlabSides sl;
             slab_sides(pl, o, inv, sl);
+            const float hi = (!ANY && prune) ? span_hi_closest(h.t, pad_abs) : sp.hi;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t c1 = info[2 * c + 1];
                 if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
-                const lanemask pm = mine & ballot64(octant_passes(sl, c));
+                const lanemask pm = mine & ballot64(octant_passes(sl, c, sp.lo, hi));
                 if (pm == 0) continue;
                 if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;
                 else st.push(info[2 * c], c1, pm);
@@ -603,7 +642,7 @@ __device__ __forceinline__ void cluster_one(const Block48& blk, const int jj, ui
 // that reach any leaf listing it.  The candidate set of every ray is the one of the plain walk -- only the number of
 // times the wave tests a triangle changes -- so the answers are the same.
 template <bool CULL, bool FAST = false>
-__device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, HitState& h) {
+__device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, Span sp, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
     WaveStack st;
     cu32_p nodes = as_const_u(T.cl_nodes);
@@ -635,7 +674,7 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
         for (int c = 0; c < 8; ++c) {
             const uint32_t c1 = info[2 * c + 1];
             if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
-            const lanemask pm = mine & ballot64(octant_passes(sl, c));
+            const lanemask pm = mine & ballot64(octant_passes(sl, c, sp.lo, sp.hi));
             if (pm == 0) continue;
             if (c1 & kChildInternal) {
                 st.push(info[2 * c], c1, pm);
@@ -674,31 +713,59 @@ __device__ __forceinline__ void traverse_clustered(const DevOctree& T, lanemask 
     }
 }
 
-// FAST (any-hit only): the caller guarantees unit-length directions and a scene within the bound of any_hit_exec.
-template <bool ANY, bool CULL, bool FAST = false>
-__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+__device__ __forceinline__ void hit_state_reset(HitState& h) {
     h.t = RT_INF;
     h.slot = 0xffffffffu;
     h.tri = 0xffffffffu;
     h.found = 0;
+    h.tie = 0;
+}
+
+// FAST (any-hit only): the caller guarantees unit-length directions and a scene within the bound of any_hit_exec.
+// clip: walk only the part of the ray that can contribute a result (Span) instead of the reference's whole line.  Any
+// hit: the segment up to the light.  Closest hit: from the origin to the best hit so far; a ray whose best distance is
+// shared by two distinct triangles is then walked a second time like the reference walks it, so that the reference's
+// rule for equal distances (first in ITS candidate list, renderer.cc:130) sees every listing leaf.  The small-tree form
+// walks whole lines: its tie rule is stated on the reached leaves themselves, and its walk is a node or a few.
+template <bool ANY, bool CULL, bool FAST = false>
+__device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, bool clip, HitState& h) {
+    hit_state_reset(h);
     const lanemask all = ballot64(valid);
     if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
     // A root that is a leaf makes every triangle a candidate without any box test (octree.cc:56-63,186-191);
     // traverse_impl handles it as a leaf entry.
-    if (T.n_flat_tris) traverse_impl<ANY, CULL, true, FAST>(T, all, o, d, t_limit, h);
-    else traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, h);
+    if (T.n_flat_tris) {  // (a tree of at most 32 leaves: its walk is one node or a few, nothing worth clipping)
+        traverse_impl<ANY, CULL, true, FAST>(T, all, o, d, t_limit, span_all(), false, h);
+        return;
+    }
+    if (ANY) {
+        traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, span_segment(o, t_limit, clip), false, h);
+        return;
+    }
+    lanemask todo = all;
+    bool pruned = clip;
+#pragma nounroll
+    for (;;) {
+        HitState w;
+        hit_state_reset(w);
+        traverse_impl<ANY, CULL, false, FAST>(T, todo, o, d, t_limit, Span{span_lo_closest(o, pruned), RT_INF}, pruned, w);
+        const bool mine = lane_of(todo);
+        h.t = mine ? w.t : h.t;
+        h.slot = mine ? w.slot : h.slot;
+        h.tri = mine ? w.tri : h.tri;
+        if (!pruned || w.tie == 0) break;
+        todo = w.tie;
+        pruned = false;
+    }
 }
 
 // Any-hit query over the clustered form (T.cl_nodes must be set; the host launches this only for such trees).
 template <bool CULL, bool FAST = false>
-__device__ __forceinline__ void traverse_any_clustered(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    h.t = RT_INF;
-    h.slot = 0xffffffffu;
-    h.tri = 0xffffffffu;
-    h.found = 0;
+__device__ __forceinline__ void traverse_any_clustered(const DevOctree& T, bool valid, f3 o, f3 d, float t_limit, bool clip, HitState& h) {
+    hit_state_reset(h);
     const lanemask all = ballot64(valid);
     if (T.root_info1 == 0 || all == 0) return;  // empty tree / no rays
-    traverse_clustered<CULL, FAST>(T, all, o, d, t_limit, h);
+    traverse_clustered<CULL, FAST>(T, all, o, d, t_limit, span_segment(o, t_limit, clip), h);
 }
 
 }  // namespace rt

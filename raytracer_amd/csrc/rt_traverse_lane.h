@@ -43,8 +43,9 @@ constexpr int kLaneMaxLevels = 17;   // internal nodes at depths 0..16
 #endif
 
 #ifdef RT_LANE_PROFILE
-// [ANY][k]: 0 cycles in descent, 1 cycles in leaf work, 2 descent steps, 3 lanes stepping (sum), 4 leaf chunks, 5 pairs, 6 waves, 7 rounds
-__device__ unsigned long long g_lane_prof[2][8];
+// [ANY][k]: 0 cycles in descent, 1 cycles in leaf work, 2 descent steps, 3 lanes stepping (sum), 4 leaf chunks, 5 pairs, 6 waves, 7 rounds,
+// sums over the descent steps of the lanes that 8 pop, 9 enter an internal node, 10 take a leaf, 11 hold leaves and wait, 12 are finished
+__device__ unsigned long long g_lane_prof[2][16];
 #define RT_PROF_ADD(k, v) do { if (__lane_id() == 0) atomicAdd(&g_lane_prof[ANY ? 1 : 0][k], (unsigned long long)(v)); } while (0)
 #endif
 
@@ -52,10 +53,24 @@ __device__ unsigned long long g_lane_prof[2][8];
 // volatile generic pointer would compile to flat accesses with a wait after each.
 typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
 
-struct LaneStackLds {  // of one wave
-    uint32_t e[kLaneMaxLevels][64];
-    uint32_t hd[64];  // which lane's leaf starts at each position of the current 64-pair chunk
+// The per-lane stack of one wave, in dynamic LDS: one entry per level of internal nodes ([level][lane]) -- the record
+// index << 8 | the octants of that node that passed the slab test and are still to be visited -- and, for the pruned
+// closest-hit walk, a lower bound of the entry distances of those octants.  hd: which lane's leaf starts at each position
+// of the current 64-pair chunk.
+struct LaneStack {
+    lds_vu32* e;
+    lds_vu32* lb;
+    lds_vu32* hd;
 };
+// Words of dynamic LDS one wave needs for a tree with `levels` levels of internal nodes.
+__host__ __device__ constexpr uint32_t lane_stack_words(uint32_t levels, bool closest) { return 64u + levels * 64u * (closest ? 2u : 1u); }
+__device__ __forceinline__ LaneStack lane_stack(uint32_t* wave_base, uint32_t levels) {
+    LaneStack s;
+    s.hd = (lds_vu32*)wave_base;
+    s.e = (lds_vu32*)(wave_base + 64);
+    s.lb = (lds_vu32*)(wave_base + 64 + levels * 64u);
+    return s;
+}
 
 // Wave-wide inclusive scans in six DPP steps (no LDS traffic): shifts by 1, 2, 4, 8 inside each row of 16 lanes (lanes
 // shifted in from outside the row read 0), then lane 15 of row 0 / 2 is added into row 1 / 3 (row_bcast:15) and lane 31
@@ -84,13 +99,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
     return x;
 }
 
-// Slab tests of the 8 octants of node `rec` for this lane's ray: bit o set iff octant o is non-empty and passes
-// (collision_detection.h:71-86 per octant; the plane products are shared between octants, see NodeRec).
-__device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ nodes, uint32_t rec, f3 o, f3 inv) {
+// Slab tests of the 8 octants of node `rec` for this lane's ray (collision_detection.h:71-86 per octant; the plane
+// products are shared between octants, see NodeRec), in the ray's own order: bit k of the result stands for octant
+// c = k ^ flip, where flip has the bit of every axis along which the ray runs backwards (1 / dir < 0) -- so that
+// ascending k is front to back.  The reference swaps the two products of an axis when 1 / dir < 0; picking, per axis,
+// the near and the far plane of the nearer and of the farther child BEFORE the multiplication gives the same products
+// from the same operands at the same number of selects.  [lo, hi]: the part of the ray that is walked (Span).
+// LB: *lb_rest = a lower bound of the entry distance of every passing octant but the nearest (see below).
+// The same tests with the octants in their own numbering (bit o = octant o), for the task-pool form.
+__device__ __forceinline__ uint32_t lane_node_pass_natural(const NodeRec* __restrict__ nodes, uint32_t rec, f3 o, f3 inv, float lo, float hi) {
     const float4* p = reinterpret_cast<const float4*>(nodes + rec);
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    const float lo[3][2] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}};
-    const float hi[3][2] = {{q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}};
+    const float plo[3][2] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}};
+    const float phi[3][2] = {{q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}};
     const uint32_t nonempty = __float_as_uint(q3.x);
     float tn[3][2], tf[3][2];
 #pragma unroll
@@ -98,8 +119,8 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
         const float oo = comp(o, ax), ii = comp(inv, ax);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            float t0 = (lo[ax][b] - oo) * ii;
-            float t1 = (hi[ax][b] - oo) * ii;
+            float t0 = (plo[ax][b] - oo) * ii;
+            float t1 = (phi[ax][b] - oo) * ii;
             if (ii < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
             tn[ax][b] = t0;
             tf[ax][b] = t1;
@@ -109,7 +130,7 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-        float t_min = slab_max(-RT_INF, tn[0][bx]), t_max = slab_min(RT_INF, tf[0][bx]);
+        float t_min = slab_max(lo, tn[0][bx]), t_max = slab_min(hi, tf[0][bx]);
         t_min = slab_max(t_min, tn[1][by]);
         t_max = slab_min(t_max, tf[1][by]);
         t_min = slab_max(t_min, tn[2][bz]);
@@ -119,33 +140,88 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
     return pass & nonempty;
 }
 
-// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  `stk` is the wave's LDS stack.
+__device__ __forceinline__ uint32_t ray_flip(f3 inv) { return (inv.x < 0.0f ? 4u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 1u : 0u); }
+template <bool LB>
+__device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ nodes, uint32_t rec, f3 o, f3 inv, uint32_t flip, float lo, float hi,
+                                                   float* lb_rest) {
+    const float4* p = reinterpret_cast<const float4*>(nodes + rec);
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const float plo[3][2] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}};
+    const float phi[3][2] = {{q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}};
+    // the non-empty octants in this ray's order: NodeRec::ordered[flip]
+    const uint32_t table = (flip & 4u) ? __float_as_uint(q3.w) : __float_as_uint(q3.z);
+    const uint32_t nonempty = (table >> ((flip & 3u) * 8u)) & 0xffu;
+    float tn[3][2], tf[3][2];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float oo = comp(o, ax), ii = comp(inv, ax);
+        const bool neg = (flip & (4u >> ax)) != 0u;  // = (ii < 0), see ray_flip
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float near_plane = neg ? phi[ax][k ^ 1] : plo[ax][k];
+            const float far_plane = neg ? plo[ax][k ^ 1] : phi[ax][k];
+            tn[ax][k] = (near_plane - oo) * ii;
+            tf[ax][k] = (far_plane - oo) * ii;
+        }
+    }
+    uint32_t pass = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int kx = (k >> 2) & 1, ky = (k >> 1) & 1, kz = k & 1;
+        float t_min = slab_max(lo, tn[0][kx]), t_max = slab_min(hi, tf[0][kx]);
+        t_min = slab_max(t_min, tn[1][ky]);
+        t_max = slab_min(t_max, tf[1][ky]);
+        t_min = slab_max(t_min, tn[2][kz]);
+        t_max = slab_min(t_max, tf[2][kz]);
+        pass |= (t_max >= t_min) ? (1u << k) : 0u;
+    }
+    pass &= nonempty;
+    if (LB) {
+        // Per axis the near product of the farther child is never below the nearer child's (same multiplier, ordered
+        // planes; a NaN product counts as -inf on both sides of the comparison), so an octant's entry distance
+        // t_min(k) = max(lo, tn[0][kx], tn[1][ky], tn[2][kz]) does not decrease when a bit of k is set.  The octants that
+        // remain after the nearest passing one therefore all enter at or beyond t_min(AND of their indices): one more
+        // evaluation instead of a minimum over eight.  An octant with t_min > hi' fails the slab test under any upper
+        // bound hi' -- that is what lets a stack entry be dropped unseen once the best hit is closer than its bound.
+        const uint32_t rest = pass & (pass - 1u);
+        const bool ux = (rest & 0x0fu) == 0u, uy = (rest & 0x33u) == 0u, uz = (rest & 0x55u) == 0u;
+        float b = slab_max(lo, ux ? tn[0][1] : tn[0][0]);
+        b = slab_max(b, uy ? tn[1][1] : tn[1][0]);
+        b = slab_max(b, uz ? tn[2][1] : tn[2][0]);
+        *lb_rest = b;
+    }
+    return pass;
+}
+
+// One walk of the rays with `valid` set.  For ANY, t_limit is the distance to the light.  `stk` is the wave's LDS stack.
+// sp: the part of the ray whose boxes are walked; prune (closest hit): its upper end follows the best distance and
+// `tie` returns the lanes whose best distance was met by two distinct triangles.
 // FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
-template <bool ANY, bool CULL, bool FAST = false>
-__device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& stk, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    h.t = RT_INF;
-    h.slot = 0xffffffffu;
-    h.tri = 0xffffffffu;
-    h.found = 0;
-    if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
+template <bool ANY, bool CULL, bool FAST>
+__device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, Span sp,
+                                                   bool prune, HitState& h, bool& found_out, bool& tie_out) {
+    constexpr bool LB = !ANY;
     const uint32_t tid = __lane_id();
     const f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
+    const uint32_t flip = ray_flip(inv);
+    const float pad_abs = span_pad_abs(o);
     bool active = valid;
-    bool found = false;
+    bool found = false, tie = false;
     constexpr bool kTwo = ANY ? (RT_LANE_TWO_LEAVES_ANY != 0) : (RT_LANE_TWO_LEAVES_CLOSEST != 0);
     uint32_t leaf_slot = 0, leaf_left = 0;    // the leaf the lane holds
     uint32_t leaf_slot2 = 0, leaf_left2 = 0;  // a second one (kTwo)
     uint32_t cur_rec = 0, cur_pending = 0;
-    int sp = 0;
+    float cur_lb = -RT_INF;  // closest hit: no pending octant of cur_rec is entered before this distance
+    int sp_n = 0;
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
         leaf_slot = T.root_info0;
         leaf_left = active ? T.root_info1 : 0u;
     } else {
         cur_rec = T.root_info0;
-        cur_pending = active ? lane_node_pass(T.nodes, cur_rec, o, inv) : 0u;
+        cur_pending = active ? lane_node_pass<LB>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, &cur_lb) : 0u;
     }
 #ifdef RT_LANE_PROFILE
-    unsigned long long pa = 0, pb = 0, psteps = 0, plan = 0, pch = 0, ppairs = 0, prounds = 0;
+    unsigned long long pa = 0, pb = 0, psteps = 0, plan = 0, pch = 0, ppairs = 0, prounds = 0, ppop = 0, pint = 0, pleaf = 0, phold = 0, pdone = 0;
 #endif
     for (;;) {
 #ifdef RT_LANE_PROFILE
@@ -161,28 +237,41 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
 #ifdef RT_LANE_PROFILE
             ++psteps; plan += __builtin_popcountll(searching);
+            ppop += __builtin_popcountll(ballot64(can_search && cur_pending == 0));
+            phold += __builtin_popcountll(holding);
+            pdone += __builtin_popcountll(ballot64(!active && leaf_left == 0));
 #endif
             if (can_search) {
-                if (cur_pending == 0) {
-                    if (sp == 0) {
-                        active = false;
-                    } else {
-                        --sp;
-                        const uint32_t e = stk.e[sp][tid];
-                        cur_rec = e >> 8;
-                        cur_pending = e & 0xffu;
+                const float hi = (!ANY && prune) ? span_hi_closest(h.t, pad_abs) : sp.hi;
+                // a lane that has used up its node first returns to the last node with octants left, in the same step
+                if (cur_pending == 0 && sp_n != 0) {
+                    --sp_n;
+                    const uint32_t e = stk.e[sp_n * 64 + tid];
+                    cur_rec = e >> 8;
+                    cur_pending = e & 0xffu;
+                    if (LB) {
+                        cur_lb = __uint_as_float(stk.lb[sp_n * 64 + tid]);
+                        if (cur_lb > hi) cur_pending = 0;  // every octant of the entry lies beyond the best hit
                     }
+                }
+                if (cur_pending == 0) {
+                    if (sp_n == 0) active = false;
                 } else {
-                    const uint32_t c = (uint32_t)__builtin_ctz(cur_pending);
+                    const uint32_t k = (uint32_t)__builtin_ctz(cur_pending);  // the nearest pending octant
                     cur_pending &= cur_pending - 1;
-                    const uint2 info = *reinterpret_cast<const uint2*>(&T.nodes[cur_rec].info[c][0]);
+                    const uint2 info = *reinterpret_cast<const uint2*>(&T.nodes[cur_rec].info[k ^ flip][0]);
+#ifdef RT_LANE_PROFILE
+                    pint += __builtin_popcountll(ballot64((info.y & kChildInternal) != 0));
+                    pleaf += __builtin_popcountll(ballot64((info.y & kChildInternal) == 0));
+#endif
                     if (info.y & kChildInternal) {
                         if (cur_pending != 0) {
-                            stk.e[sp][tid] = (cur_rec << 8) | cur_pending;
-                            ++sp;
+                            stk.e[sp_n * 64 + tid] = (cur_rec << 8) | cur_pending;
+                            if (LB) stk.lb[sp_n * 64 + tid] = __float_as_uint(cur_lb);
+                            ++sp_n;
                         }
                         cur_rec = info.x;
-                        cur_pending = lane_node_pass(T.nodes, cur_rec, o, inv);
+                        cur_pending = lane_node_pass<LB>(T.nodes, cur_rec, o, inv, flip, sp.lo, hi, &cur_lb);
                     } else if (kTwo && leaf_left != 0) {
                         leaf_slot2 = info.x;
                         leaf_left2 = info.y;
@@ -210,7 +299,7 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            lds_vu32* hd = (lds_vu32*)stk.hd;
+            lds_vu32* hd = stk.hd;
             lanemask decided = 0;  // any-hit: owners that found an occluder earlier in this round
             for (uint32_t base = 0; base < total; base += 64) {
                 hd[lane] = 0;
@@ -235,8 +324,18 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                     if (p - o_excl >= first_n) slot = o_slot2 + (p - o_excl - first_n);
                 }
                 const bool on = pair && !((decided >> L) & 1ull);
-                const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
-                const f3 a = mk(g[0], g[1], g[2]), e1 = mk(g[3], g[4], g[5]), e2 = mk(g[6], g[7], g[8]);
+                f3 a, e1, e2;
+                uint32_t tri = 0;
+                if (ANY) {  // geometry only (36 bytes)
+                    const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
+                    a = mk(g[0], g[1], g[2]); e1 = mk(g[3], g[4], g[5]); e2 = mk(g[6], g[7], g[8]);
+                } else {  // the whole record: the triangle index tells a second listing of the best triangle from a tie
+                    const LeafTri* g = T.slots + (on ? slot : 0u);
+                    const float4 r0 = reinterpret_cast<const float4*>(g)[0], r1 = reinterpret_cast<const float4*>(g)[1];
+                    const float2 r2 = reinterpret_cast<const float2*>(g)[4];
+                    a = mk(r0.x, r0.y, r0.z); e1 = mk(r0.w, r1.x, r1.y); e2 = mk(r1.z, r1.w, r2.x);
+                    tri = __float_as_uint(r2.y);
+                }
                 float t = RT_INF;
                 lanemask hit;
                 if constexpr (ANY && FAST && kHandScheduledTests) {
@@ -265,10 +364,14 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
                         m &= m - 1ull;
                         const float tc = __shfl(t, (int)c, 64);
                         const uint32_t sc = __shfl(slot, (int)c, 64);
+                        const uint32_t trc = __shfl(tri, (int)c, 64);
                         // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
-                        const bool b = has && (tc < h.t || (tc == h.t && sc < h.slot));
+                        const bool less = has && tc < h.t, same = has && tc == h.t;
+                        tie = (tie && !less) || (same && trc != h.tri);  // two distinct triangles at the best distance
+                        const bool b = less || (same && sc < h.slot);
                         h.t = b ? tc : h.t;
                         h.slot = b ? sc : h.slot;
+                        h.tri = b ? trc : h.tri;
                     }
                 }
             }
@@ -281,11 +384,42 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, LaneStackLds& 
 #endif
         }
     }
-    if (ANY) h.found = ballot64(found);
-    else if (h.slot != 0xffffffffu) h.tri = T.slots[h.slot].tri;  // the winner's triangle index, read once
+    found_out = found;
+    tie_out = tie;
 #ifdef RT_LANE_PROFILE
     RT_PROF_ADD(0, pa); RT_PROF_ADD(1, pb); RT_PROF_ADD(2, psteps); RT_PROF_ADD(3, plan); RT_PROF_ADD(4, pch); RT_PROF_ADD(5, ppairs); RT_PROF_ADD(6, 1); RT_PROF_ADD(7, prounds);
+    RT_PROF_ADD(8, ppop); RT_PROF_ADD(9, pint); RT_PROF_ADD(10, pleaf); RT_PROF_ADD(11, phold); RT_PROF_ADD(12, pdone);
 #endif
+}
+
+// valid: this lane carries a ray.  clip: see traverse<> in rt_traverse.h -- any-hit rays walk the segment up to the
+// light; closest-hit rays walk front to back up to their best hit, and a ray whose best distance two distinct
+// triangles share is walked once more like the reference walks it (whole line, no pruning), which settles the tie by
+// the reference's own rule.
+template <bool ANY, bool CULL, bool FAST = false>
+__device__ __forceinline__ void traverse_lane(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, bool clip,
+                                              HitState& h) {
+    hit_state_reset(h);
+    if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
+    bool found = false, tie = false;
+    if (ANY) {
+        traverse_lane_walk<ANY, CULL, FAST>(T, stk, valid, o, d, t_limit, span_segment(o, t_limit, clip), false, h, found, tie);
+        h.found = ballot64(found);
+        return;
+    }
+    bool todo = valid, pruned = clip;
+#pragma nounroll
+    for (;;) {
+        HitState w;
+        hit_state_reset(w);
+        traverse_lane_walk<ANY, CULL, FAST>(T, stk, todo, o, d, t_limit, Span{span_lo_closest(o, pruned), RT_INF}, pruned, w, found, tie);
+        h.t = todo ? w.t : h.t;
+        h.slot = todo ? w.slot : h.slot;
+        h.tri = todo ? w.tri : h.tri;
+        if (!pruned || ballot64(tie) == 0) break;
+        todo = tie;
+        pruned = false;
+    }
 }
 
 }  // namespace rt

@@ -56,19 +56,18 @@ struct PoolLds {  // of one wave
     uint32_t hd[64];
 };
 
-// valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.  The root must be an internal node
-// and leaves must hold fewer than 2^26 triangles (the host selects this form only then).
-// FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
-template <bool ANY, bool CULL, bool FAST = false>
-__device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
-    h.t = RT_INF;
-    h.slot = 0xffffffffu;
-    h.tri = 0xffffffffu;
-    h.found = 0;
+// One walk of the rays with `valid` set.  For ANY, t_limit is the distance to the light.
+// sp: the part of the ray whose boxes are walked; prune (closest hit): its upper end follows the ray's best distance
+// (read from best[] when a task comes up) and `tie` returns the rays whose best distance two distinct triangles share.
+template <bool ANY, bool CULL, bool FAST>
+__device__ __forceinline__ void traverse_pool_walk(const DevOctree& T, PoolLds& lds, bool valid, f3 o, f3 d, float t_limit, Span sp, bool prune,
+                                                   HitState& h, lanemask& tie) {
     const lanemask vm = ballot64(valid);
-    if (T.root_info1 == 0 || vm == 0) return;  // empty tree / no rays
+    tie = 0;
+    if (vm == 0) return;
     const uint32_t lane = __lane_id();
     const f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
+    const float pad_abs = span_pad_abs(o);
     lds_vu32* nstk = (lds_vu32*)lds.nodes;
     lds_vu32* lslot = (lds_vu32*)lds.leaf_slot;
     lds_vu32* lcount = (lds_vu32*)lds.leaf_count;
@@ -121,8 +120,18 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
                 const f3 rd = mk(__shfl(d.x, (int)ray, 64), __shfl(d.y, (int)ray, 64), __shfl(d.z, (int)ray, 64));
                 const uint32_t slot = o_slot + (p - o_excl);
                 const bool on = pair && !(ANY && ((decided >> ray) & 1ull));
-                const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
-                const f3 a = mk(g[0], g[1], g[2]), e1 = mk(g[3], g[4], g[5]), e2 = mk(g[6], g[7], g[8]);
+                f3 a, e1, e2;
+                uint32_t tri = 0;
+                if (ANY) {  // geometry only (36 bytes)
+                    const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
+                    a = mk(g[0], g[1], g[2]); e1 = mk(g[3], g[4], g[5]); e2 = mk(g[6], g[7], g[8]);
+                } else {  // the whole record: the triangle index tells a second listing of the best triangle from a tie
+                    const LeafTri* g = T.slots + (on ? slot : 0u);
+                    const float4 r0 = reinterpret_cast<const float4*>(g)[0], r1 = reinterpret_cast<const float4*>(g)[1];
+                    const float2 r2 = reinterpret_cast<const float2*>(g)[4];
+                    a = mk(r0.x, r0.y, r0.z); e1 = mk(r0.w, r1.x, r1.y); e2 = mk(r1.z, r1.w, r2.x);
+                    tri = __float_as_uint(r2.y);
+                }
                 float t = RT_INF;
                 lanemask hit;
                 if constexpr (ANY && FAST && kHandScheduledTests) {
@@ -139,9 +148,20 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
                         good &= good - 1ull;
                         decided |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)ray, g);
                     }
-                } else if (lane_of(hit) && t < RT_INF) {
-                    // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
-                    atomicMin(&lds.best[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)slot);
+                } else {
+                    bool shared = false;
+                    if (lane_of(hit) && t < RT_INF) {
+                        // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
+                        const unsigned long long old = atomicMin(&lds.best[ray], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)slot);
+                        // the same distance from another slot: a second listing of the same triangle, or a tie of two triangles
+                        if ((uint32_t)(old >> 32) == __float_as_uint(t) && (uint32_t)old != slot) shared = T.slots[(uint32_t)old].tri != tri;
+                    }
+                    lanemask sh = ballot64(shared);
+                    while (sh != 0) {
+                        const int g = __builtin_ctzll(sh);
+                        sh &= sh - 1ull;
+                        tie |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)ray, g);
+                    }
                 }
             }
 #ifdef RT_LANE_PROFILE
@@ -166,12 +186,20 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
         const bool work = lane < k && !(ANY && ((decided >> ray) & 1ull));
         const f3 ro = mk(__shfl(o.x, (int)ray, 64), __shfl(o.y, (int)ray, 64), __shfl(o.z, (int)ray, 64));
         const f3 ri = mk(__shfl(inv.x, (int)ray, 64), __shfl(inv.y, (int)ray, 64), __shfl(inv.z, (int)ray, 64));
+        const float r_lo = __shfl(sp.lo, (int)ray, 64);
+        float r_hi;
+        if (!ANY && prune) {  // the ray's best distance so far (keys are (bits of t) << 32 | slot; all ones = none)
+            const uint32_t tb = (uint32_t)(__hip_atomic_load(&lds.best[ray], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 32);
+            r_hi = tb == 0xffffffffu ? RT_INF : span_hi_closest(__uint_as_float(tb), __shfl(pad_abs, (int)ray, 64));
+        } else {
+            r_hi = __shfl(sp.hi, (int)ray, 64);
+        }
         uint32_t pass_internal = 0, pass_leaf = 0;
         uint4 i0 = make_uint4(0, 0, 0, 0), i1 = i0, i2 = i0, i3 = i0;  // info[0..1], [2..3], [4..5], [6..7]
         if (work) {
             const uint4* ip = reinterpret_cast<const uint4*>(T.nodes + rec) + 4;
             i0 = ip[0]; i1 = ip[1]; i2 = ip[2]; i3 = ip[3];
-            const uint32_t pass = lane_node_pass(T.nodes, rec, ro, ri);
+            const uint32_t pass = lane_node_pass_natural(T.nodes, rec, ro, ri, r_lo, r_hi);
             const uint32_t internal = ((i0.y >> 31) & 1u) | ((i0.w >> 31) << 1) | ((i1.y >> 31) << 2) | ((i1.w >> 31) << 3) |
                                       ((i2.y >> 31) << 4) | ((i2.w >> 31) << 5) | ((i3.y >> 31) << 6) | ((i3.w >> 31) << 7);
             pass_internal = pass & internal;
@@ -222,7 +250,37 @@ __device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, 
             h.slot = (uint32_t)key;
             h.tri = T.slots[h.slot].tri;
         }
+        tie &= vm;
+        __builtin_amdgcn_wave_barrier();  // (the next walk of this wave reuses the pool)
     }
 }
+
+// valid: this lane carries a ray.  clip: see traverse<> in rt_traverse.h.  The root must be an internal node and leaves
+// must hold fewer than 2^26 triangles (the host selects this form only then).
+// FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
+template <bool ANY, bool CULL, bool FAST = false>
+__device__ __forceinline__ void traverse_pool(const DevOctree& T, PoolLds& lds, bool valid, f3 o, f3 d, float t_limit, bool clip, HitState& h) {
+    hit_state_reset(h);
+    if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
+    lanemask tie = 0;
+    if (ANY) {
+        traverse_pool_walk<ANY, CULL, FAST>(T, lds, valid, o, d, t_limit, span_segment(o, t_limit, clip), false, h, tie);
+        return;
+    }
+    bool todo = valid, pruned = clip;
+#pragma nounroll
+    for (;;) {
+        HitState w;
+        hit_state_reset(w);
+        traverse_pool_walk<ANY, CULL, FAST>(T, lds, todo, o, d, t_limit, Span{span_lo_closest(o, pruned), RT_INF}, pruned, w, tie);
+        h.t = todo ? w.t : h.t;
+        h.slot = todo ? w.slot : h.slot;
+        h.tri = todo ? w.tri : h.tri;
+        if (!pruned || tie == 0) break;
+        todo = lane_of(tie);
+        pruned = false;
+    }
+}
+
 
 }  // namespace rt

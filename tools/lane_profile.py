@@ -28,7 +28,7 @@ kw = dict(fov=0.6, width=W, height=H, spp=wl["spp"], spt=wl["spt"], render_type=
 frame = torch.zeros((H + 64, W, 3), dtype=torch.float32, device="cuda")
 cfg = rt.make_render_config(**kw)
 lib = _capi.lib()
-out = (ctypes.c_ulonglong * 48)()
+out = (ctypes.c_ulonglong * 64)()
 ads.render(cfg, out_ptr=frame.data_ptr())
 torch.cuda.synchronize()
 assert lib.rt_debug_lane_profile(out) == 0
@@ -36,20 +36,22 @@ ads.render(cfg, out_ptr=frame.data_ptr())
 torch.cuda.synchronize()
 assert lib.rt_debug_lane_profile(out) == 0
 for k, name in ((0, "closest"), (1, "any-hit")):
-    a, b, steps, lanes, chunks, pairs, waves, rounds = [int(out[k * 8 + i]) for i in range(8)]
+    a, b, steps, lanes, chunks, pairs, waves, rounds, npop, nint, nleaf, nhold, ndone = [int(out[k * 16 + i]) for i in range(13)]
     if waves == 0:
         continue
+    print(f"{name}: per descent step, lanes that pop {npop / max(steps, 1):.1f}, enter a node {nint / max(steps, 1):.1f}, take a leaf {nleaf / max(steps, 1):.1f}, "
+          f"hold and wait {nhold / max(steps, 1):.1f}, are finished {ndone / max(steps, 1):.1f}")
     print(f"{name}: waves {waves}  cycles/wave descent {a / waves:.0f} leaf {b / waves:.0f} | per wave: rounds {rounds / waves:.1f} "
           f"descent steps {steps / waves:.1f} (lanes stepping {lanes / max(steps, 1):.1f}) leaf chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
           f"| cycles per descent step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
 for k, name in ((0, "closest"), (1, "any-hit")):
-    a, b, steps, tasks, chunks, pairs, waves, phases = [int(out[32 + k * 8 + i]) for i in range(8)]
+    a, b, steps, tasks, chunks, pairs, waves, phases = [int(out[48 + k * 8 + i]) for i in range(8)]
     if waves == 0:
         continue
     print(f"pool {name}: waves {waves}  cycles/wave node steps {a / waves:.0f} leaf {b / waves:.0f} | per wave: node steps {steps / waves:.1f} "
           f"(tasks per step {tasks / max(steps, 1):.1f}) leaf phases {phases / waves:.1f} chunks {chunks / waves:.1f} pairs {pairs / waves:.0f} "
           f"| cycles per node step {a / max(steps, 1):.0f}, per leaf chunk {b / max(chunks, 1):.0f}, pairs per chunk {pairs / max(chunks, 1):.1f}")
-w = [int(out[16 + i]) for i in range(16)]
+w = [int(out[32 + i]) for i in range(16)]
 if w[0]:
     print(f"wave any-hit, plain walk: waves {w[0]}  per wave: node visits {w[1] / w[0]:.2f} leaf visits {w[2] / w[0]:.2f} triangle tests started {w[3] / w[0]:.2f}")
 if w[8]:
