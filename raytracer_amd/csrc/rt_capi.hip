@@ -118,7 +118,7 @@ struct SearchWork {
 
 constexpr int kMaxTimed = 64;
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
-constexpr bool kClipDefault = false;
+constexpr bool kClipDefault = true;  // RT_CLIP=0: every ray walks the whole line like the reference (same results)
 constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots are walked by the wave together, whatever the rays
 
 // Launches KERNEL<cull, mode>(args...) for run-time cull / traversal mode.

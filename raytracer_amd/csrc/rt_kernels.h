@@ -60,7 +60,7 @@ struct TraverseLds<MODE_POOL> {
     PoolLds s;
 };
 // The per-lane form keeps its stacks in dynamic LDS, sized at launch for the tree's depth (lane_stack_words).
-extern __shared__ uint32_t rt_dyn_lds[];
+extern __shared__ __attribute__((aligned(16))) uint32_t rt_dyn_lds[];  // (64-bit LDS atomics of the per-lane closest-hit walk)
 
 // Launch options of the traversal kernels, packed into one kernel argument (the wave-together forms sit at the edge of
 // their scalar register budget): bits 0..3 `sparse` (see ray_index), bit 4 `clip` (walk only the part of a ray that can
@@ -94,7 +94,7 @@ __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds
     const bool clip = opts_clip(opts);
     if constexpr (MODE == MODE_LANE) {
         const uint32_t levels = opts_levels(opts);
-        const LaneStack stk = lane_stack(rt_dyn_lds + (threadIdx.x >> 6) * lane_stack_words(levels, !ANY), levels);
+        const LaneStack stk = lane_stack(rt_dyn_lds + (threadIdx.x >> 6) * lane_stack_words(levels, !ANY), levels, !ANY);
         traverse_lane<ANY, CULL, ANY && FAST>(T, stk, valid, o, d, t_limit, clip, h);
     } else if constexpr (MODE == MODE_POOL) {
         traverse_pool<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, clip, h);

@@ -61,14 +61,17 @@ struct LaneStack {
     lds_vu32* e;
     lds_vu32* lb;
     lds_vu32* hd;
+    unsigned long long* best;  // closest hit: per home lane the smallest (bits of t) << 32 | slot published so far
 };
 // Words of dynamic LDS one wave needs for a tree with `levels` levels of internal nodes.
-__host__ __device__ constexpr uint32_t lane_stack_words(uint32_t levels, bool closest) { return 64u + levels * 64u * (closest ? 2u : 1u); }
-__device__ __forceinline__ LaneStack lane_stack(uint32_t* wave_base, uint32_t levels) {
+__host__ __device__ constexpr uint32_t lane_stack_words(uint32_t levels, bool closest) { return 64u + (closest ? 128u : 0u) + levels * 64u * (closest ? 2u : 1u); }
+__device__ __forceinline__ LaneStack lane_stack(uint32_t* wave_base, uint32_t levels, bool closest) {
     LaneStack s;
-    s.hd = (lds_vu32*)wave_base;
-    s.e = (lds_vu32*)(wave_base + 64);
-    s.lb = (lds_vu32*)(wave_base + 64 + levels * 64u);
+    s.best = (unsigned long long*)wave_base;  // (closest-hit launches only; so is lb)
+    uint32_t* rest = wave_base + (closest ? 128u : 0u);
+    s.hd = (lds_vu32*)rest;
+    s.e = (lds_vu32*)(rest + 64);
+    s.lb = (lds_vu32*)(rest + 64 + levels * 64u);
     return s;
 }
 
@@ -193,32 +196,52 @@ __device__ __forceinline__ uint32_t lane_node_pass(const NodeRec* __restrict__ n
     return pass;
 }
 
-// One walk of the rays with `valid` set.  For ANY, t_limit is the distance to the light.  `stk` is the wave's LDS stack.
-// sp: the part of the ray whose boxes are walked; prune (closest hit): its upper end follows the best distance and
-// `tie` returns the lanes whose best distance was met by two distinct triangles.
-// FAST (any-hit only): unit-length directions in a scene within the bound of any_hit_exec.
-template <bool ANY, bool CULL, bool FAST>
-__device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, Span sp,
-                                                   bool prune, HitState& h, bool& found_out, bool& tie_out) {
-    constexpr bool LB = !ANY;
+// In-wave work stealing (RT_LANE_STEAL).  The rays of a wave need very different numbers of descent
+// steps -- a shadow ray that skims a finely tessellated surface passes hundreds of small octants, its neighbours a
+// dozen -- and a wave lasts as long as its slowest lane: on a 1.3 M-triangle scene 38 of 64 lanes sat finished through
+// the average descent step.  The octants a ray still has to visit are independent subtrees (an any-hit answer is an OR
+// over them), so a finished lane takes over the OLDEST stack entry of a busy lane -- the subtree nearest the root --
+// together with a copy of that lane's ray, and walks it with its own stack.  Answers are kept per home lane of a ray
+// (`owner`): an occluder found by any lane decides the ray for all lanes that work on it; closest hits are merged with a
+// 64-bit minimum per home lane in LDS ((bits of t) << 32 | leaf slot: the order of the keys is the tie rule).
+#ifndef RT_LANE_STEAL
+#define RT_LANE_STEAL 1
+#endif
+#ifndef RT_LANE_STEAL_MIN_IDLE
+#define RT_LANE_STEAL_MIN_IDLE 8
+#endif
+// Closest-hit rays: off.  Their ordered, pruned walks are short and alike (47 of 64 lanes take part in the average
+// descent step without it), and the merge of the lanes' results costs 12 vector registers -- 5 instead of 7 waves per
+// SIMD: 2.24 against 2.04 ms for the closest-hit passes of a 4K frame of a 1.3 M-triangle scene.
+#ifndef RT_LANE_STEAL_CLOSEST
+#define RT_LANE_STEAL_CLOSEST 0
+#endif
+
+__device__ __forceinline__ uint32_t lanes_below(lanemask m) {  // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Any-hit walk of the rays with `valid` set; returns the lanes whose ray has an occluder.  t_limit: distance to the light.
+template <bool CULL, bool FAST>
+__device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, Span sp) {
+    [[maybe_unused]] constexpr bool ANY = true;  // (the profiling macros index by it)
     const uint32_t tid = __lane_id();
-    const f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
-    const uint32_t flip = ray_flip(inv);
-    const float pad_abs = span_pad_abs(o);
+    f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
+    uint32_t flip = ray_flip(inv);
+    uint32_t owner = tid;    // the home lane of the ray this lane works on
+    lanemask decided = 0;    // home lanes whose ray has an occluder
     bool active = valid;
-    bool found = false, tie = false;
-    constexpr bool kTwo = ANY ? (RT_LANE_TWO_LEAVES_ANY != 0) : (RT_LANE_TWO_LEAVES_CLOSEST != 0);
+    constexpr bool kTwo = RT_LANE_TWO_LEAVES_ANY != 0;
     uint32_t leaf_slot = 0, leaf_left = 0;    // the leaf the lane holds
     uint32_t leaf_slot2 = 0, leaf_left2 = 0;  // a second one (kTwo)
     uint32_t cur_rec = 0, cur_pending = 0;
-    float cur_lb = -RT_INF;  // closest hit: no pending octant of cur_rec is entered before this distance
-    int sp_n = 0;
+    int sp_n = 0, sb = 0;  // the lane's stack entries are [sb, sp_n)
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
         leaf_slot = T.root_info0;
         leaf_left = active ? T.root_info1 : 0u;
     } else {
         cur_rec = T.root_info0;
-        cur_pending = active ? lane_node_pass<LB>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, &cur_lb) : 0u;
+        cur_pending = active ? lane_node_pass<false>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, nullptr) : 0u;
     }
 #ifdef RT_LANE_PROFILE
     unsigned long long pa = 0, pb = 0, psteps = 0, plan = 0, pch = 0, ppairs = 0, prounds = 0, ppop = 0, pint = 0, pleaf = 0, phold = 0, pdone = 0;
@@ -227,14 +250,52 @@ __device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const Lan
 #ifdef RT_LANE_PROFILE
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- phase A: active lanes without a leaf take descent steps.  The phase ends when they all hold a leaf
-        // (or are finished), or earlier once few of them are still searching: those resume in the next round.
+        // ---- phase A: active lanes without a leaf take descent steps (see traverse_lane_walk)
         for (;;) {
             const bool can_search = active && (kTwo ? leaf_left2 == 0 : leaf_left == 0);
             const lanemask searching = ballot64(can_search);
             if (searching == 0) break;
             const lanemask holding = ballot64(leaf_left != 0 && !can_search);  // lanes that only wait for the leaf phase
             if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
+#if RT_LANE_STEAL
+            {
+                const bool idle = !active && leaf_left == 0;
+                const lanemask idle_m = ballot64(idle);
+                if (__builtin_popcountll(idle_m) >= RT_LANE_STEAL_MIN_IDLE) {
+                    const bool donor = active && sp_n > sb;
+                    const lanemask donor_m = ballot64(donor);
+                    if (donor_m != 0) {
+                        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m), n_donor = (uint32_t)__builtin_popcountll(donor_m);
+                        const uint32_t rank_d = lanes_below(donor_m), rank_i = lanes_below(idle_m);
+                        const bool gives = donor && rank_d < n_idle, thief = idle && rank_i < n_donor;
+                        if (gives) stk.hd[rank_d] = tid;  // the k-th donor serves the k-th idle lane
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t from = thief ? stk.hd[rank_i] : tid;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t e = stk.e[(uint32_t)__shfl(sb, (int)from, 64) * 64u + from];  // (a lane's own column if it steals nothing)
+                        const f3 t_o = mk(__shfl(o.x, (int)from, 64), __shfl(o.y, (int)from, 64), __shfl(o.z, (int)from, 64));
+                        const f3 t_d = mk(__shfl(d.x, (int)from, 64), __shfl(d.y, (int)from, 64), __shfl(d.z, (int)from, 64));
+                        const f3 t_inv = mk(__shfl(inv.x, (int)from, 64), __shfl(inv.y, (int)from, 64), __shfl(inv.z, (int)from, 64));
+                        const uint32_t t_flip = __shfl(flip, (int)from, 64), t_owner = __shfl(owner, (int)from, 64);
+                        const float t_tl = __shfl(t_limit, (int)from, 64), t_lo = __shfl(sp.lo, (int)from, 64), t_hi = __shfl(sp.hi, (int)from, 64);
+                        if (thief) {
+                            o = t_o; d = t_d; inv = t_inv; flip = t_flip; owner = t_owner;
+                            t_limit = t_tl; sp.lo = t_lo; sp.hi = t_hi;
+                            cur_rec = e >> 8;
+                            cur_pending = e & 0xffu;
+                            active = true;
+                            sp_n = sb = 0;
+                        }
+                        __builtin_amdgcn_wave_barrier();  // the entries have been read before their lanes may reuse the places
+                        if (gives) {
+                            ++sb;
+                            if (sb == sp_n) sb = sp_n = 0;
+                        }
+                        continue;
+                    }
+                }
+            }
+#endif
 #ifdef RT_LANE_PROFILE
             ++psteps; plan += __builtin_popcountll(searching);
             ppop += __builtin_popcountll(ballot64(can_search && cur_pending == 0));
@@ -242,20 +303,16 @@ __device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const Lan
             pdone += __builtin_popcountll(ballot64(!active && leaf_left == 0));
 #endif
             if (can_search) {
-                const float hi = (!ANY && prune) ? span_hi_closest(h.t, pad_abs) : sp.hi;
                 // a lane that has used up its node first returns to the last node with octants left, in the same step
-                if (cur_pending == 0 && sp_n != 0) {
+                if (cur_pending == 0 && sp_n != sb) {
                     --sp_n;
                     const uint32_t e = stk.e[sp_n * 64 + tid];
                     cur_rec = e >> 8;
                     cur_pending = e & 0xffu;
-                    if (LB) {
-                        cur_lb = __uint_as_float(stk.lb[sp_n * 64 + tid]);
-                        if (cur_lb > hi) cur_pending = 0;  // every octant of the entry lies beyond the best hit
-                    }
+                    if (sp_n == sb) sb = sp_n = 0;
                 }
                 if (cur_pending == 0) {
-                    if (sp_n == 0) active = false;
+                    active = false;  // (the stack is empty: the pop above would have refilled the node)
                 } else {
                     const uint32_t k = (uint32_t)__builtin_ctz(cur_pending);  // the nearest pending octant
                     cur_pending &= cur_pending - 1;
@@ -267,11 +324,10 @@ __device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const Lan
                     if (info.y & kChildInternal) {
                         if (cur_pending != 0) {
                             stk.e[sp_n * 64 + tid] = (cur_rec << 8) | cur_pending;
-                            if (LB) stk.lb[sp_n * 64 + tid] = __float_as_uint(cur_lb);
                             ++sp_n;
                         }
                         cur_rec = info.x;
-                        cur_pending = lane_node_pass<LB>(T.nodes, cur_rec, o, inv, flip, sp.lo, hi, &cur_lb);
+                        cur_pending = lane_node_pass<false>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, nullptr);
                     } else if (kTwo && leaf_left != 0) {
                         leaf_slot2 = info.x;
                         leaf_left2 = info.y;
@@ -287,20 +343,231 @@ __device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const Lan
         pa += t1 - t0;
 #endif
         if (ballot64(active || leaf_left != 0) == 0) break;  // a finished lane may still hold leaves to test
-        // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane owns
-        // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
-        // lane i of the wave tests pair base + i: it fetches the owner's ray through lane shuffles and the triangle
-        // record itself -- neighbouring lanes read neighbouring records, so the loads coalesce -- and the owners
-        // collect the results from the ballot (any-hit) or from the hit lanes of their range (closest hit; ranges
-        // are in slot order, so the tie rule is the lane order).
+        // ---- phase B: the (ray, triangle) pairs of the held leaves, 64 per step (see traverse_lane_walk)
         {
-            const uint32_t lane = __lane_id();
+            const uint32_t lane = tid;
             const uint32_t cnt = leaf_left + (kTwo ? leaf_left2 : 0u);
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             lds_vu32* hd = stk.hd;
-            lanemask decided = 0;  // any-hit: owners that found an occluder earlier in this round
+            for (uint32_t base = 0; base < total; base += 64) {
+                hd[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (cnt != 0 && excl >= base && excl < base + 64) hd[excl - base] = lane + 1;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t own = hd[lane];
+                __builtin_amdgcn_wave_barrier();
+                const lanemask cont = ballot64(cnt != 0 && excl < base && incl > base);  // a leaf continuing from the last chunk
+                const uint32_t carry = cont ? (uint32_t)__builtin_ctzll(cont) + 1u : 0u;
+                own = wave_inclusive_max(own);
+                own = own < carry ? carry : own;
+                const uint32_t p = base + lane;
+                const bool pair = p < total;
+                const uint32_t L = pair ? own - 1u : lane;  // the lane that holds the pair's leaf
+                const uint32_t o_excl = __shfl(excl, (int)L, 64), o_slot = __shfl(leaf_slot, (int)L, 64);
+                const f3 ro = mk(__shfl(o.x, (int)L, 64), __shfl(o.y, (int)L, 64), __shfl(o.z, (int)L, 64));
+                const f3 rd = mk(__shfl(d.x, (int)L, 64), __shfl(d.y, (int)L, 64), __shfl(d.z, (int)L, 64));
+                const uint32_t r_owner = __shfl(owner, (int)L, 64);
+                uint32_t slot = o_slot + (p - o_excl);
+                if (kTwo) {  // past the holder's first leaf: its second one
+                    const uint32_t first_n = __shfl(leaf_left, (int)L, 64), o_slot2 = __shfl(leaf_slot2, (int)L, 64);
+                    if (p - o_excl >= first_n) slot = o_slot2 + (p - o_excl - first_n);
+                }
+                const bool on = pair && !((decided >> r_owner) & 1ull);
+                const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
+                const f3 a = mk(g[0], g[1], g[2]), e1 = mk(g[3], g[4], g[5]), e2 = mk(g[6], g[7], g[8]);
+                float t = RT_INF;
+                lanemask good;
+                if constexpr (FAST && kHandScheduledTests) {
+                    good = any_hit_exec_pairs<CULL>(ballot64(on), ro, rd, a, e1, e2, __shfl(t_limit, (int)L, 64));  // renderer.cc:302 included
+                } else {
+                    good = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
+                    if (good != 0) good &= ballot64(t < __shfl(t_limit, (int)L, 64));  // renderer.cc:302
+                }
+                // the occluders' rays are decided, whichever lanes work on them
+                while (good != 0) {
+                    const int gl = __builtin_ctzll(good);
+                    good &= good - 1ull;
+                    decided |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)r_owner, gl);
+                }
+            }
+            leaf_left = 0;
+            leaf_left2 = 0;
+            if ((decided >> owner) & 1ull) {  // this lane's ray is decided: drop what is left of it
+                active = false;
+                cur_pending = 0;
+                sp_n = sb = 0;
+            }
+#ifdef RT_LANE_PROFILE
+            pb += __builtin_amdgcn_s_memtime() - t1;
+            pch += (total + 63) / 64; ppairs += total; ++prounds;
+#endif
+        }
+    }
+#ifdef RT_LANE_PROFILE
+    RT_PROF_ADD(0, pa); RT_PROF_ADD(1, pb); RT_PROF_ADD(2, psteps); RT_PROF_ADD(3, plan); RT_PROF_ADD(4, pch); RT_PROF_ADD(5, ppairs); RT_PROF_ADD(6, 1); RT_PROF_ADD(7, prounds);
+    RT_PROF_ADD(8, ppop); RT_PROF_ADD(9, pint); RT_PROF_ADD(10, pleaf); RT_PROF_ADD(11, phold); RT_PROF_ADD(12, pdone);
+#endif
+    return decided;
+}
+
+// Closest-hit walk of the rays with `valid` set.  lo: lower end of the part of the ray that is walked; prune: the upper
+// end follows the ray's best distance (the smaller of this lane's own best and the best any lane has published for the
+// ray).  Returns in `ties` the home lanes whose best distance was met by two distinct triangles.
+template <bool CULL>
+__device__ __forceinline__ void traverse_lane_closest(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float lo, bool prune,
+                                                      HitState& h, lanemask& ties_out) {
+    [[maybe_unused]] constexpr bool ANY = false;  // (the profiling macros index by it)
+    constexpr bool kSteal = (RT_LANE_STEAL != 0) && (RT_LANE_STEAL_CLOSEST != 0);
+    const uint32_t tid = __lane_id();
+    f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
+    uint32_t flip = ray_flip(inv);
+    float pad_abs = span_pad_abs(o);
+    uint32_t owner = tid;  // the home lane of the ray this lane works on
+    lanemask ties = 0;     // home lanes with two distinct triangles at the best distance
+    bool active = valid;
+    float bt = RT_INF;     // this lane's best candidate for that ray: distance, leaf slot, triangle
+    uint32_t bslot = 0xffffffffu, btri = 0xffffffffu;
+    float bound = RT_INF;  // the best distance published for the ray by any lane
+    bool improved = false, tie_l = false;
+    constexpr bool kTwo = RT_LANE_TWO_LEAVES_CLOSEST != 0;
+    uint32_t leaf_slot = 0, leaf_left = 0;    // the leaf the lane holds
+    uint32_t leaf_slot2 = 0, leaf_left2 = 0;  // a second one (kTwo)
+    uint32_t cur_rec = 0, cur_pending = 0;
+    float cur_lb = -RT_INF;  // no pending octant of cur_rec is entered before this distance
+    int sp_n = 0, sb = 0;    // the lane's stack entries are [sb, sp_n)
+    if (kSteal) stk.best[tid] = ~0ull;
+    if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
+        leaf_slot = T.root_info0;
+        leaf_left = active ? T.root_info1 : 0u;
+    } else {
+        cur_rec = T.root_info0;
+        cur_pending = active ? lane_node_pass<true>(T.nodes, cur_rec, o, inv, flip, lo, RT_INF, &cur_lb) : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+#ifdef RT_LANE_PROFILE
+    unsigned long long pa = 0, pb = 0, psteps = 0, plan = 0, pch = 0, ppairs = 0, prounds = 0, ppop = 0, pint = 0, pleaf = 0, phold = 0, pdone = 0;
+#endif
+    for (;;) {
+#ifdef RT_LANE_PROFILE
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- phase A: active lanes without a leaf take descent steps.  The phase ends when they all hold a leaf
+        // (or are finished), or earlier once few of them are still searching: those resume in the next round.
+        for (;;) {
+            const bool can_search = active && (kTwo ? leaf_left2 == 0 : leaf_left == 0);
+            const lanemask searching = ballot64(can_search);
+            if (searching == 0) break;
+            const lanemask holding = ballot64(leaf_left != 0 && !can_search);  // lanes that only wait for the leaf phase
+            if (__builtin_popcountll(searching) * RT_LANE_A_NUM < __builtin_popcountll(holding) * RT_LANE_A_DEN) break;
+            if constexpr (kSteal) {
+                const bool idle = !active && leaf_left == 0;
+                const lanemask idle_m = ballot64(idle);
+                if (__builtin_popcountll(idle_m) >= RT_LANE_STEAL_MIN_IDLE) {
+                    const bool donor = active && sp_n > sb;
+                    const lanemask donor_m = ballot64(donor);
+                    if (donor_m != 0) {
+                        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m), n_donor = (uint32_t)__builtin_popcountll(donor_m);
+                        const uint32_t rank_d = lanes_below(donor_m), rank_i = lanes_below(idle_m);
+                        const bool gives = donor && rank_d < n_idle, thief = idle && rank_i < n_donor;
+                        if (gives) stk.hd[rank_d] = tid;  // the k-th donor serves the k-th idle lane
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t from = thief ? stk.hd[rank_i] : tid;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t at = (uint32_t)__shfl(sb, (int)from, 64) * 64u + from;  // (a lane's own column if it steals nothing)
+                        const uint32_t e = stk.e[at], e_lb = stk.lb[at];
+                        const f3 t_o = mk(__shfl(o.x, (int)from, 64), __shfl(o.y, (int)from, 64), __shfl(o.z, (int)from, 64));
+                        const f3 t_d = mk(__shfl(d.x, (int)from, 64), __shfl(d.y, (int)from, 64), __shfl(d.z, (int)from, 64));
+                        const f3 t_inv = mk(__shfl(inv.x, (int)from, 64), __shfl(inv.y, (int)from, 64), __shfl(inv.z, (int)from, 64));
+                        const uint32_t t_flip = __shfl(flip, (int)from, 64), t_owner = __shfl(owner, (int)from, 64);
+                        const float t_lo = __shfl(lo, (int)from, 64), t_pad = __shfl(pad_abs, (int)from, 64);
+                        if (thief) {  // (an idle lane has published all it found for its last ray)
+                            o = t_o; d = t_d; inv = t_inv; flip = t_flip; owner = t_owner;
+                            lo = t_lo; pad_abs = t_pad;
+                            cur_rec = e >> 8;
+                            cur_pending = e & 0xffu;
+                            cur_lb = __uint_as_float(e_lb);
+                            active = true;
+                            sp_n = sb = 0;
+                            bt = RT_INF;
+                            bslot = btri = 0xffffffffu;
+                            const uint32_t tb = (uint32_t)(__hip_atomic_load(&stk.best[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 32);
+                            bound = tb == 0xffffffffu ? RT_INF : __uint_as_float(tb);
+                        }
+                        __builtin_amdgcn_wave_barrier();  // the entries have been read before their lanes may reuse the places
+                        if (gives) {
+                            ++sb;
+                            if (sb == sp_n) sb = sp_n = 0;
+                        }
+                        continue;
+                    }
+                }
+            }
+#ifdef RT_LANE_PROFILE
+            ++psteps; plan += __builtin_popcountll(searching);
+            ppop += __builtin_popcountll(ballot64(can_search && cur_pending == 0));
+            phold += __builtin_popcountll(holding);
+            pdone += __builtin_popcountll(ballot64(!active && leaf_left == 0));
+#endif
+            if (can_search) {
+                const float hi = prune ? span_hi_closest(bt < bound ? bt : bound, pad_abs) : RT_INF;
+                // a lane that has used up its node first returns to the last node with octants left, in the same step
+                if (cur_pending == 0 && sp_n != sb) {
+                    --sp_n;
+                    const uint32_t e = stk.e[sp_n * 64 + tid];
+                    cur_rec = e >> 8;
+                    cur_pending = e & 0xffu;
+                    cur_lb = __uint_as_float(stk.lb[sp_n * 64 + tid]);
+                    if (cur_lb > hi) cur_pending = 0;  // every octant of the entry lies beyond the best hit
+                    if (sp_n == sb) sb = sp_n = 0;
+                }
+                if (cur_pending == 0) {
+                    if (sp_n == sb) active = false;
+                } else {
+                    const uint32_t k = (uint32_t)__builtin_ctz(cur_pending);  // the nearest pending octant
+                    cur_pending &= cur_pending - 1;
+                    const uint2 info = *reinterpret_cast<const uint2*>(&T.nodes[cur_rec].info[k ^ flip][0]);
+#ifdef RT_LANE_PROFILE
+                    pint += __builtin_popcountll(ballot64((info.y & kChildInternal) != 0));
+                    pleaf += __builtin_popcountll(ballot64((info.y & kChildInternal) == 0));
+#endif
+                    if (info.y & kChildInternal) {
+                        if (cur_pending != 0) {
+                            stk.e[sp_n * 64 + tid] = (cur_rec << 8) | cur_pending;
+                            stk.lb[sp_n * 64 + tid] = __float_as_uint(cur_lb);
+                            ++sp_n;
+                        }
+                        cur_rec = info.x;
+                        cur_pending = lane_node_pass<true>(T.nodes, cur_rec, o, inv, flip, lo, hi, &cur_lb);
+                    } else if (kTwo && leaf_left != 0) {
+                        leaf_slot2 = info.x;
+                        leaf_left2 = info.y;
+                    } else {
+                        leaf_slot = info.x;
+                        leaf_left = info.y;
+                    }
+                }
+            }
+        }
+#ifdef RT_LANE_PROFILE
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        pa += t1 - t0;
+#endif
+        if (ballot64(active || leaf_left != 0) == 0) break;  // a finished lane may still hold leaves to test
+        // ---- phase B: all (ray, triangle) pairs of the leaves the lanes hold, 64 pairs per step whatever lane holds
+        // them.  Pair p of the round belongs to the lane whose leaf covers position p of the concatenated leaves;
+        // lane i of the wave tests pair base + i: it fetches the holder's ray through lane shuffles and the triangle
+        // record itself -- neighbouring lanes read neighbouring records, so the loads coalesce -- and the holders
+        // collect the results from the hit lanes of their range (ranges are in slot order, so the tie rule is the lane
+        // order).
+        {
+            const uint32_t lane = tid;
+            const uint32_t cnt = leaf_left + (kTwo ? leaf_left2 : 0u);
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            const uint32_t excl = incl - cnt;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            lds_vu32* hd = stk.hd;
             for (uint32_t base = 0; base < total; base += 64) {
                 hd[lane] = 0;
                 __builtin_amdgcn_wave_barrier();
@@ -319,73 +586,89 @@ __device__ __forceinline__ void traverse_lane_walk(const DevOctree& T, const Lan
                 const f3 ro = mk(__shfl(o.x, (int)L, 64), __shfl(o.y, (int)L, 64), __shfl(o.z, (int)L, 64));
                 const f3 rd = mk(__shfl(d.x, (int)L, 64), __shfl(d.y, (int)L, 64), __shfl(d.z, (int)L, 64));
                 uint32_t slot = o_slot + (p - o_excl);
-                if (kTwo) {  // past the owner's first leaf: its second one
+                if (kTwo) {  // past the holder's first leaf: its second one
                     const uint32_t first_n = __shfl(leaf_left, (int)L, 64), o_slot2 = __shfl(leaf_slot2, (int)L, 64);
                     if (p - o_excl >= first_n) slot = o_slot2 + (p - o_excl - first_n);
                 }
-                const bool on = pair && !((decided >> L) & 1ull);
-                f3 a, e1, e2;
-                uint32_t tri = 0;
-                if (ANY) {  // geometry only (36 bytes)
-                    const float* g = T.slot_geom + (size_t)(on ? slot : 0u) * 9;
-                    a = mk(g[0], g[1], g[2]); e1 = mk(g[3], g[4], g[5]); e2 = mk(g[6], g[7], g[8]);
-                } else {  // the whole record: the triangle index tells a second listing of the best triangle from a tie
-                    const LeafTri* g = T.slots + (on ? slot : 0u);
-                    const float4 r0 = reinterpret_cast<const float4*>(g)[0], r1 = reinterpret_cast<const float4*>(g)[1];
-                    const float2 r2 = reinterpret_cast<const float2*>(g)[4];
-                    a = mk(r0.x, r0.y, r0.z); e1 = mk(r0.w, r1.x, r1.y); e2 = mk(r1.z, r1.w, r2.x);
-                    tri = __float_as_uint(r2.y);
-                }
+                // the whole record: the triangle index tells a second listing of the best triangle from a tie
+                const LeafTri* g = T.slots + (pair ? slot : 0u);
+                const float4 r0 = reinterpret_cast<const float4*>(g)[0], r1 = reinterpret_cast<const float4*>(g)[1];
+                const float2 r2 = reinterpret_cast<const float2*>(g)[4];
+                const f3 a = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                const uint32_t tri = __float_as_uint(r2.y);
                 float t = RT_INF;
-                lanemask hit;
-                if constexpr (ANY && FAST && kHandScheduledTests) {
-                    hit = any_hit_exec_pairs<CULL>(ballot64(on), ro, rd, a, e1, e2, __shfl(t_limit, (int)L, 64));  // renderer.cc:302 included
-                } else {
-                    hit = ray_triangle<CULL>(ballot64(on), ro, rd, a, e1, e2, t);
-                }
+                const lanemask hit = ray_triangle<CULL>(ballot64(pair), ro, rd, a, e1, e2, t);
                 if (hit == 0) continue;
-                // this lane's leaf covers positions [lo, hi) of the chunk
+                // this lane's leaves cover positions [rlo, rhi) of the chunk
                 const bool here = cnt != 0 && excl < base + 64 && incl > base;
-                const uint32_t lo = excl > base ? excl - base : 0u;
-                const uint32_t hi = incl - base < 64u ? incl - base : 64u;
-                const lanemask below_hi = hi >= 64u ? ~0ull : ((1ull << hi) - 1ull);
-                const lanemask range = here ? (below_hi & ~((1ull << lo) - 1ull)) : 0ull;
-                if (ANY) {
-                    lanemask good = hit;
-                    if constexpr (!(FAST && kHandScheduledTests)) good = hit & ballot64(t < __shfl(t_limit, (int)L, 64));  // renderer.cc:302
-                    const bool f = (good & range) != 0;
-                    found = found || f;
-                    decided |= ballot64(f);
-                } else {
-                    lanemask m = hit & range;
-                    while (ballot64(m != 0) != 0) {
-                        const bool has = m != 0;
-                        const uint32_t c = has ? (uint32_t)__builtin_ctzll(m) : lane;
-                        m &= m - 1ull;
-                        const float tc = __shfl(t, (int)c, 64);
-                        const uint32_t sc = __shfl(slot, (int)c, 64);
-                        const uint32_t trc = __shfl(tri, (int)c, 64);
-                        // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
-                        const bool less = has && tc < h.t, same = has && tc == h.t;
-                        tie = (tie && !less) || (same && trc != h.tri);  // two distinct triangles at the best distance
-                        const bool b = less || (same && sc < h.slot);
-                        h.t = b ? tc : h.t;
-                        h.slot = b ? sc : h.slot;
-                        h.tri = b ? trc : h.tri;
-                    }
+                const uint32_t rlo = excl > base ? excl - base : 0u;
+                const uint32_t rhi = incl - base < 64u ? incl - base : 64u;
+                const lanemask below_hi = rhi >= 64u ? ~0ull : ((1ull << rhi) - 1ull);
+                const lanemask range = here ? (below_hi & ~((1ull << rlo) - 1ull)) : 0ull;
+                lanemask m = hit & range;
+                while (ballot64(m != 0) != 0) {
+                    const bool has = m != 0;
+                    const uint32_t c = has ? (uint32_t)__builtin_ctzll(m) : lane;
+                    m &= m - 1ull;
+                    const float tc = __shfl(t, (int)c, 64);
+                    const uint32_t sc = __shfl(slot, (int)c, 64);
+                    const uint32_t trc = __shfl(tri, (int)c, 64);
+                    // renderer.cc:130: strictly smaller t wins; equal t keeps the smaller global slot
+                    const bool less = has && tc < bt, same = has && tc == bt;
+                    tie_l = (tie_l && !less) || (same && trc != btri);  // two distinct triangles at the best distance
+                    const bool b = less || (same && sc < bslot);
+                    bt = b ? tc : bt;
+                    bslot = b ? sc : bslot;
+                    btri = b ? trc : btri;
+                    improved = improved || b;
                 }
             }
-            if (ANY && found) active = false;  // this ray is decided
             leaf_left = 0;
             leaf_left2 = 0;
+            // publish: what this lane found joins the ray's best, and every lane learns the ray's best distance
+            if constexpr (kSteal) {
+            if (improved) {
+                const unsigned long long old = atomicMin(&stk.best[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bslot);
+                // the same distance from another slot: a second listing of the same triangle, or a tie of two triangles
+                if ((uint32_t)(old >> 32) == __float_as_uint(bt) && (uint32_t)old != bslot && T.slots[(uint32_t)old].tri != btri) tie_l = true;
+                improved = false;
+            }
+            lanemask tm = ballot64(tie_l);
+            tie_l = false;
+            while (tm != 0) {
+                const int gl = __builtin_ctzll(tm);
+                tm &= tm - 1ull;
+                ties |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)owner, gl);
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t tb = (uint32_t)(__hip_atomic_load(&stk.best[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 32);
+                bound = tb == 0xffffffffu ? RT_INF : __uint_as_float(tb);
+            }
+            }
 #ifdef RT_LANE_PROFILE
             pb += __builtin_amdgcn_s_memtime() - t1;
             pch += (total + 63) / 64; ppairs += total; ++prounds;
 #endif
         }
     }
-    found_out = found;
-    tie_out = tie;
+    if constexpr (kSteal) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long key = __hip_atomic_load(&stk.best[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (valid && key != ~0ull) {
+            h.t = __uint_as_float((uint32_t)(key >> 32));
+            h.slot = (uint32_t)key;
+            h.tri = T.slots[h.slot].tri;
+        }
+        __builtin_amdgcn_wave_barrier();  // (a second walk of this wave resets best[])
+        ties_out = ties;
+    } else {  // every lane has walked its own ray
+        h.t = bt;
+        h.slot = bslot;
+        h.tri = btri;
+        ties_out = ballot64(tie_l);
+    }
 #ifdef RT_LANE_PROFILE
     RT_PROF_ADD(0, pa); RT_PROF_ADD(1, pb); RT_PROF_ADD(2, psteps); RT_PROF_ADD(3, plan); RT_PROF_ADD(4, pch); RT_PROF_ADD(5, ppairs); RT_PROF_ADD(6, 1); RT_PROF_ADD(7, prounds);
     RT_PROF_ADD(8, ppop); RT_PROF_ADD(9, pint); RT_PROF_ADD(10, pleaf); RT_PROF_ADD(11, phold); RT_PROF_ADD(12, pdone);
@@ -401,24 +684,23 @@ __device__ __forceinline__ void traverse_lane(const DevOctree& T, const LaneStac
                                               HitState& h) {
     hit_state_reset(h);
     if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
-    bool found = false, tie = false;
-    if (ANY) {
-        traverse_lane_walk<ANY, CULL, FAST>(T, stk, valid, o, d, t_limit, span_segment(o, t_limit, clip), false, h, found, tie);
-        h.found = ballot64(found);
-        return;
-    }
-    bool todo = valid, pruned = clip;
+    if constexpr (ANY) {
+        h.found = traverse_lane_any<CULL, FAST>(T, stk, valid, o, d, t_limit, span_segment(o, t_limit, clip));
+    } else {
+        bool todo = valid, pruned = clip;
 #pragma nounroll
-    for (;;) {
-        HitState w;
-        hit_state_reset(w);
-        traverse_lane_walk<ANY, CULL, FAST>(T, stk, todo, o, d, t_limit, Span{span_lo_closest(o, pruned), RT_INF}, pruned, w, found, tie);
-        h.t = todo ? w.t : h.t;
-        h.slot = todo ? w.slot : h.slot;
-        h.tri = todo ? w.tri : h.tri;
-        if (!pruned || ballot64(tie) == 0) break;
-        todo = tie;
-        pruned = false;
+        for (;;) {
+            HitState w;
+            hit_state_reset(w);
+            lanemask ties = 0;
+            traverse_lane_closest<CULL>(T, stk, todo, o, d, span_lo_closest(o, pruned), pruned, w, ties);
+            h.t = todo ? w.t : h.t;
+            h.slot = todo ? w.slot : h.slot;
+            h.tri = todo ? w.tri : h.tri;
+            if (!pruned || ties == 0) break;
+            todo = lane_of(ties);
+            pruned = false;
+        }
     }
 }
 
