@@ -226,6 +226,15 @@ typedef struct rt_render_stats {
  * stores them before write_color); only the pixels of this call's bands are written. */
 int rt_render(rt_ads* ads, const rt_render_config* cfg, float* out_rgb, int mem, rt_render_stats* stats, void* stream);
 
+/* How many sub-frames a rt_render call renders concurrently (1..8, default 1, or the value of the environment variable
+ * RT_RENDER_STREAMS at rt_ads_create).  The call's bands are dealt round-robin to n sub-frames; each has its own level
+ * buffers and runs on a HIP stream and a host thread of the library's own (the first one on the caller's stream and
+ * thread), ordered after what the caller's stream holds at the call; the call still returns when the whole frame is
+ * complete, and the image does not depend on n.  A frame of many small recursion levels is a chain of launches that
+ * each last as long as their slowest wavefront; sub-frames fill the gaps of one another.  No reference counterpart
+ * (Renderer::RenderScene, renderer.cc:37-52, is one sequential loop). */
+int rt_ads_set_render_streams(rt_ads* ads, int n);
+
 /* Primary-ray closest hits only (sample 0, no shading): per pixel t and triangle index. */
 int rt_render_primary_hits(rt_ads* ads, const rt_render_config* cfg, float* out_t, int32_t* out_tri, int mem, void* stream);
 

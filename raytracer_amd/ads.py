@@ -173,6 +173,10 @@ class GpuOctree(Ads):
         _capi.check(_capi.lib().rt_render(self._h, C.byref(cfg), _p(out), _capi.RT_MEM_HOST, C.byref(st), stream))
         return out, st
 
+    def set_render_streams(self, n):
+        """render() calls render their bands as n concurrent sub-frames on streams of the library's own (same image)."""
+        _capi.check(_capi.lib().rt_ads_set_render_streams(self._h, int(n)))
+
     def primary_hits(self, cfg):
         n = cfg.width * cfg.height
         t = np.zeros(n, np.float32)

@@ -7,7 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -117,6 +120,97 @@ struct SearchWork {
 };
 
 constexpr int kMaxTimed = 64;
+// Everything one frame in flight owns: the level buffers of the recursion, the counters, the mailboxes through which
+// the kernels tell the host the level sizes, the timing events.  A handle has one per concurrent sub-frame.
+constexpr int kMaxRenderStreams = 8;
+struct FrameCtx {
+    std::vector<Level> levels;
+    DevBuf<uint32_t> d_counters;  // one CNT_WORDS block per level
+    // what the device tells the host while a frame is in flight, in pinned host memory the kernels write directly
+    LevelSlot* h_slots = nullptr;      // one per recursion level
+    FrameTotals* h_totals = nullptr;
+    DevBuf<FrameTotals> d_totals;
+    uint32_t slot_seq = 0;
+    DevBuf<float> d_accum;
+    hipEvent_t ev[2 + 6 * kMaxTimed] = {};
+    bool events_ready = false;
+    hipStream_t own_stream = nullptr;  // sub-frames 1..: a stream of the library's own
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void release() {
+        for (auto& l : levels) l.release();
+        d_counters.release(); d_totals.release(); d_accum.release();
+        if (h_slots) (void)hipHostFree(h_slots);
+        if (h_totals) (void)hipHostFree(h_totals);
+        if (events_ready)
+            for (auto& e : ev) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        h_slots = nullptr; h_totals = nullptr; events_ready = false; own_stream = nullptr; ev_fork = ev_join = nullptr;
+    }
+};
+
+// Host threads that run the sub-frames 1.. of a rt_render call (sub-frame 0 runs on the caller's thread).  The threads
+// are started once and sleep between frames.
+class SubFramePool {
+  public:
+    explicit SubFramePool(int workers) {
+        for (int k = 0; k < workers; ++k) threads_.emplace_back([this, k] { loop(k); });
+    }
+    ~SubFramePool() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            quit_ = true;
+        }
+        cv_job_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int workers() const { return (int)threads_.size(); }
+    // Runs f(1) .. f(n - 1) on the workers and f(0) on the caller; returns when all have returned.
+    void run(int n, const std::function<void(int)>& f) {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_ = &f;
+            n_jobs_ = n;
+            pending_ = std::min(n - 1, (int)threads_.size());
+            ++generation_;
+        }
+        cv_job_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lock(m_);
+        cv_done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(int k) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_job_.wait(lock, [&] { return quit_ || (generation_ != seen && k + 1 < n_jobs_); });
+                if (quit_) return;
+                seen = generation_;
+                f = job_;
+            }
+            (*f)(k + 1);
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                --pending_;
+            }
+            cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_job_, cv_done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int n_jobs_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool quit_ = false;
+};
+
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 constexpr bool kClipDefault = true;  // RT_CLIP=0: every ray walks the whole line like the reference (same results)
 constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots are walked by the wave together, whatever the rays
@@ -219,19 +313,15 @@ struct rt_ads {
     DevBuf<MatDev> d_mats;
     DevBuf<LightDev> d_lights;
     uint32_t n_lights = 0;
-    std::vector<Level> levels;
-    DevBuf<uint32_t> d_counters;  // one CNT_WORDS block per level
-    // what the device tells the host while a frame is in flight, in pinned host memory the kernels write directly
-    LevelSlot* h_slots = nullptr;      // one per recursion level
-    FrameTotals* h_totals = nullptr;
-    DevBuf<FrameTotals> d_totals;
-    uint32_t slot_seq = 0;
-    DevBuf<float> d_accum, d_stage;
+    // rt_render: the frame is rendered as `render_streams` sub-frames (bands dealt round-robin) that run concurrently,
+    // each with its own level buffers on its own stream and host thread (frame[0]: the caller's stream and thread)
+    FrameCtx frame[kMaxRenderStreams];
+    int render_streams = 1;
+    SubFramePool* pool = nullptr;
+    DevBuf<float> d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
     SearchWork search;
     unsigned char* noalloc_scratch = nullptr;  // this device's copy of the fixed scratch array (rt_ads_search_noalloc)
-    hipEvent_t ev[2 + 6 * kMaxTimed] = {};
-    bool events_ready = false;
     rt_query_stats q{};
     bool collect_stats = false;  // run the instrumented pass for the reference-defined counters of rt_query_stats
     DevBuf<unsigned long long> d_qstats;      // QS_WORDS totals of the instrumented pass
@@ -536,6 +626,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
         return fail(RT_ERR_INVALID, "unknown builder %u", cfg->builder);
     }
     a->builder = (int)cfg->builder;
+    if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
     // the fixed scratch of rt_ads_search_noalloc: its address on this device, looked up with the device current
     {
         hipError_t e = hipSetDevice(cfg->device);
@@ -552,17 +643,13 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
 void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
+    delete a->pool;  // joins the sub-frame threads
     a->d_nodes.release(); a->d_slots.release(); a->d_slot_geom.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
-    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_counters.release(); a->d_accum.release(); a->d_stage.release(); a->d_io.release();
-    for (auto& l : a->levels) l.release();
+    a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_stage.release(); a->d_io.release();
+    for (auto& x : a->frame) x.release();
     a->search.release();
     a->d_qstats.release();
     if (a->h_qstats) (void)hipHostFree(a->h_qstats);
-    if (a->h_slots) (void)hipHostFree(a->h_slots);
-    if (a->h_totals) (void)hipHostFree(a->h_totals);
-    a->d_totals.release();
-    if (a->events_ready)
-        for (auto& e : a->ev) (void)hipEventDestroy(e);
     delete a;
 }
 
@@ -1358,10 +1445,10 @@ SceneDev scene_dev(const rt_ads* a) {
     return S;
 }
 
-int ensure_events(rt_ads* a) {
-    if (a->events_ready) return RT_OK;
-    for (auto& e : a->ev) HIP_TRY(hipEventCreate(&e));
-    a->events_ready = true;
+int ensure_events(FrameCtx& x) {
+    if (x.events_ready) return RT_OK;
+    for (auto& e : x.ev) HIP_TRY(hipEventCreate(&e));
+    x.events_ready = true;
     return RT_OK;
 }
 
@@ -1389,16 +1476,16 @@ int wait_slot(const LevelSlot* slot, uint32_t seq, hipStream_t stream) {
     }
 }
 
-int ensure_frame_mailboxes(rt_ads* a) {
-    if (!a->h_slots) {
-        HIP_TRY(hipHostMalloc((void**)&a->h_slots, kMaxLevels * sizeof(LevelSlot), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(a->h_slots, 0, kMaxLevels * sizeof(LevelSlot));
+int ensure_frame_mailboxes(FrameCtx& x) {
+    if (!x.h_slots) {
+        HIP_TRY(hipHostMalloc((void**)&x.h_slots, kMaxLevels * sizeof(LevelSlot), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(x.h_slots, 0, kMaxLevels * sizeof(LevelSlot));
     }
-    if (!a->h_totals) {
-        HIP_TRY(hipHostMalloc((void**)&a->h_totals, sizeof(FrameTotals), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(a->h_totals, 0, sizeof(FrameTotals));
+    if (!x.h_totals) {
+        HIP_TRY(hipHostMalloc((void**)&x.h_totals, sizeof(FrameTotals), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(x.h_totals, 0, sizeof(FrameTotals));
     }
-    HIP_TRY(a->d_totals.reserve(1));
+    HIP_TRY(x.d_totals.reserve(1));
     return RT_OK;
 }
 
@@ -1406,28 +1493,24 @@ int ensure_frame_mailboxes(rt_ads* a) {
 
 extern "C" {
 
-int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_render_stats* stats, void* stream_) {
-    if (!a || !c || !out_rgb) return fail(RT_ERR_INVALID, "null argument");
-    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
-    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
-    if (mem != RT_MEM_HOST && mem != RT_MEM_DEVICE) return fail(RT_ERR_INVALID, "bad mem argument");
-    if (int rc = use_device(a)) return rc;
+}  // extern "C"
+
+namespace {
+
+// One sub-frame of rt_render: the bands c->band_rank of c->band_world, rendered into the device frame buffer d_out with
+// the level buffers of `x`, on `stream`; returns after the stream has drained.  The instrumented pass (collect_stats) is
+// begun and ended by the caller.
+int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out, hipStream_t stream, rt_render_stats& st_out) {
+    if (int rc = use_device(a)) return rc;  // (a worker thread starts on device 0)
     FrameParams F;
     uint32_t n0 = 0;
     if (int rc = frame_params(a, c, F, n0)) return rc;
-    if (int rc = ensure_events(a)) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = ensure_events(x)) return rc;
     const SceneDev S = scene_dev(a);
     const uint32_t max_levels = (uint32_t)c->max_depth + 1;
-    if (a->levels.size() < max_levels) a->levels.resize(max_levels);
-    HIP_TRY(a->d_counters.reserve((size_t)max_levels * CNT_WORDS));
-    const size_t frame_floats = (size_t)c->width * c->height * 3;
-    float* d_out = out_rgb;
-    if (mem == RT_MEM_HOST) {
-        HIP_TRY(a->d_stage.reserve(frame_floats));
-        d_out = a->d_stage.p;
-    }
-    if (c->samples_per_pixel > 1) { HIP_TRY(a->d_accum.reserve((size_t)n0 * 3)); }
+    if (x.levels.size() < max_levels) x.levels.resize(max_levels);
+    HIP_TRY(x.d_counters.reserve((size_t)max_levels * CNT_WORDS));
+    if (c->samples_per_pixel > 1) { HIP_TRY(x.d_accum.reserve((size_t)n0 * 3)); }
 
     rt_render_stats st{};
     uint64_t valid_pixels = 0;  // of this call's bands, per sample
@@ -1438,8 +1521,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     // intervals per class are taken per call.
     enum { CLS_OTHER = 0, CLS_CLOSEST = 1, CLS_SHADOW = 2, CLS_SHADE = 3 };
     constexpr int kMaxMarks = 6 * kMaxTimed;
-    hipEvent_t* ev_total = a->ev;
-    hipEvent_t* ev_mark = a->ev + 2;
+    hipEvent_t* ev_total = x.ev;
+    hipEvent_t* ev_mark = x.ev + 2;
     int n_marks = 0, n_cls[4] = {0, 0, 0, 0};
     uint8_t mark_cls[kMaxMarks];
     bool last_timed = false;
@@ -1456,22 +1539,19 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         if (want) ++n_cls[cls];
         return RT_OK;
     };
-    if (int rc = ensure_frame_mailboxes(a)) return rc;
+    if (int rc = ensure_frame_mailboxes(x)) return rc;
     HIP_TRY(hipEventRecord(ev_total[0], stream));
     const dim3 block(256);
-    if (a->collect_stats) {
-        if (int rc = stats_begin(a, stream)) return rc;
-    }
     // The frame runs without a host synchronisation.  Level sizes stay on the device: the closest-hit pass of level L
     // reads its ray count from level L-1's counters and its last block publishes (hits, upper bound of the next level's
     // rays) into pinned host memory; the host waits for that flag only after it has queued the level's any-hit pass, so
     // the device never idles, and sizes the shading pass and the next level's buffers with it.  Launch grids of a level
     // come from the published upper bound; surplus threads leave at once.
-    const uint32_t seq_base = a->slot_seq;
-    a->slot_seq = seq_base + (uint32_t)c->samples_per_pixel + 1u;  // the next frame starts beyond every sequence number of this one
-    hipLaunchKernelGGL(k_frame_begin, dim3(1), block, 0, stream, a->d_counters.p, max_levels, a->h_slots, seq_base, a->d_totals.p);
+    const uint32_t seq_base = x.slot_seq;
+    x.slot_seq = seq_base + (uint32_t)c->samples_per_pixel + 1u;  // the next frame starts beyond every sequence number of this one
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), block, 0, stream, x.d_counters.p, max_levels, x.h_slots, seq_base, x.d_totals.p);
     HIP_TRY(hipGetLastError());
-    a->h_totals->secondary_rays = a->h_totals->shadow_rays = 0;
+    x.h_totals->secondary_rays = x.h_totals->shadow_rays = 0;
     uint32_t level_seq[kMaxLevels];
     for (auto& q : level_seq) q = seq_base;
     const bool lit = (c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG) && a->n_lights > 0 && c->samples_per_triangle > 0;
@@ -1481,13 +1561,13 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         F.spp_sample = (uint32_t)s;
         uint32_t cap = n0, levels = 0;  // cap: upper bound of the level's ray count (exact for level 0)
         for (uint32_t L = 0; L < max_levels && cap > 0; ++L) {
-            Level& lv = a->levels[L];
+            Level& lv = x.levels[L];
             HIP_TRY(lv.reserve(cap, L > 0));
             lv.n = cap;
             level_n[L] = cap;
-            uint32_t* cnt = a->d_counters.p + (size_t)L * CNT_WORDS;
+            uint32_t* cnt = x.d_counters.p + (size_t)L * CNT_WORDS;
             const uint32_t* n_dev = L > 0 ? cnt - CNT_WORDS + CNT_NEXT : nullptr;
-            const LevelSlot* slot = a->h_slots + L;
+            const LevelSlot* slot = x.h_slots + L;
             const uint32_t seq = ++level_seq[L];  // CNT_SEQ of the level after this launch
             const int mode_c = traversal_mode(a, L == 0, false, cap);
             const uint32_t sparse_c = pool_sparse(a, mode_c, cap, 1);
@@ -1568,8 +1648,8 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             RayRec* next_rays = nullptr;
             uint32_t next_cap = 0;
             if (L + 1 < max_levels && spawn > 0) {
-                HIP_TRY(a->levels[L + 1].reserve(spawn, true));
-                next_rays = a->levels[L + 1].rays.p;
+                HIP_TRY(x.levels[L + 1].reserve(spawn, true));
+                next_rays = x.levels[L + 1].rays.p;
                 next_cap = spawn;
             }
             const dim3 grid_s((n_work + 255) / 256);
@@ -1583,14 +1663,14 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         if (int rc = mark(CLS_OTHER)) return rc;  // the resolve passes are not timed
         st.levels = std::max(st.levels, levels);
         for (uint32_t L = levels; L-- > 1;) {
-            Level& lv = a->levels[L];
-            const uint32_t* n_dev = a->d_counters.p + (size_t)(L - 1) * CNT_WORDS + CNT_NEXT;
-            hipLaunchKernelGGL(k_resolve, dim3((level_n[L] + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, n_dev, a->levels[L - 1].out.p);
+            Level& lv = x.levels[L];
+            const uint32_t* n_dev = x.d_counters.p + (size_t)(L - 1) * CNT_WORDS + CNT_NEXT;
+            hipLaunchKernelGGL(k_resolve, dim3((level_n[L] + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, n_dev, x.levels[L - 1].out.p);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, a->levels[0].out.p, n0, a->d_accum.p, d_out);
+        hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, x.levels[0].out.p, n0, x.d_accum.p, d_out);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_roll_counters, dim3(1), block, 0, stream, a->d_counters.p, max_levels, a->d_totals.p, a->h_totals);
+        hipLaunchKernelGGL(k_roll_counters, dim3(1), block, 0, stream, x.d_counters.p, max_levels, x.d_totals.p, x.h_totals);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_total[1], stream));
@@ -1600,6 +1680,103 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         uint64_t rows = 0;
         for (int b = c->band_rank; b < bands; b += c->band_world) rows += (uint64_t)std::min(8, c->height - b * 8);
         st.primary_rays = rows * (uint64_t)c->width * (uint64_t)c->samples_per_pixel;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev_total[0], ev_total[1]));
+    st.ms_total = ms;
+    for (int k = 0; k + 1 < n_marks; ++k) {
+        if (mark_cls[k] == CLS_OTHER) continue;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_mark[k], ev_mark[k + 1]));
+        if (mark_cls[k] == CLS_CLOSEST) st.ms_closest += ms;
+        else if (mark_cls[k] == CLS_SHADOW) st.ms_shadow += ms;
+        else st.ms_shade += ms;
+    }
+    st.secondary_rays = x.h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
+    st.shadow_rays = x.h_totals->shadow_rays;
+    st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
+    st_out = st;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_ads_set_render_streams(rt_ads* a, int n) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (n < 1 || n > kMaxRenderStreams) return fail(RT_ERR_INVALID, "render streams must be in [1,%d]", kMaxRenderStreams);
+    a->render_streams = n;
+    return RT_OK;
+}
+
+int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_render_stats* stats, void* stream_) {
+    if (!a || !c || !out_rgb) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    if (mem != RT_MEM_HOST && mem != RT_MEM_DEVICE) return fail(RT_ERR_INVALID, "bad mem argument");
+    if (int rc = use_device(a)) return rc;
+    {
+        FrameParams F;
+        uint32_t n0 = 0;
+        if (int rc = frame_params(a, c, F, n0)) return rc;  // argument checks
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t frame_floats = (size_t)c->width * c->height * 3;
+    float* d_out = out_rgb;
+    if (mem == RT_MEM_HOST) {
+        HIP_TRY(a->d_stage.reserve(frame_floats));
+        d_out = a->d_stage.p;
+    }
+    // The sub-frames: this call's bands dealt round-robin once more.  Short frames are chains of small launches, each
+    // as long as its slowest wave; independent sub-frames on streams of their own fill the gaps of one another.  The
+    // instrumented pass keeps one set of totals, so it runs the frame as one piece.
+    const int bands_mine = std::max(0, ((c->height + 7) / 8 - c->band_rank + c->band_world - 1) / c->band_world);
+    int n_sub = a->collect_stats ? 1 : std::min(a->render_streams, std::max(bands_mine, 1));
+    if ((uint64_t)c->band_world * (uint64_t)n_sub > 0x7fffffffull) n_sub = 1;
+    if (a->collect_stats) {
+        if (int rc = stats_begin(a, stream)) return rc;
+    }
+    rt_render_stats sub_stats[kMaxRenderStreams] = {};
+    int sub_rc[kMaxRenderStreams] = {};
+    char sub_err[kMaxRenderStreams][sizeof g_err] = {};
+    if (n_sub == 1) {
+        sub_rc[0] = render_bands(a, a->frame[0], c, d_out, stream, sub_stats[0]);
+        if (sub_rc[0]) return sub_rc[0];
+    } else {
+        if (!a->pool || a->pool->workers() < n_sub - 1) {
+            delete a->pool;
+            a->pool = new SubFramePool(kMaxRenderStreams - 1);
+        }
+        // sub-frames 1.. start after what the caller has queued on its stream, and the caller's stream continues after them
+        if (!a->frame[0].ev_fork) HIP_TRY(hipEventCreateWithFlags(&a->frame[0].ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(a->frame[0].ev_fork, stream));
+        for (int k = 1; k < n_sub; ++k) {
+            FrameCtx& x = a->frame[k];
+            if (!x.own_stream) HIP_TRY(hipStreamCreateWithFlags(&x.own_stream, hipStreamNonBlocking));
+            if (!x.ev_join) HIP_TRY(hipEventCreateWithFlags(&x.ev_join, hipEventDisableTiming));
+            HIP_TRY(hipStreamWaitEvent(x.own_stream, a->frame[0].ev_fork, 0));
+        }
+        const std::function<void(int)> job = [&](int k) {
+            rt_render_config sub = *c;
+            sub.band_world = c->band_world * n_sub;
+            sub.band_rank = c->band_rank + k * c->band_world;
+            sub_rc[k] = render_bands(a, a->frame[k], &sub, d_out, k == 0 ? stream : a->frame[k].own_stream, sub_stats[k]);
+            if (sub_rc[k]) snprintf(sub_err[k], sizeof sub_err[k], "%s", g_err);  // (the message is the worker thread's)
+        };
+        a->pool->run(n_sub, job);
+        for (int k = 0; k < n_sub; ++k)
+            if (sub_rc[k]) return fail(sub_rc[k], "%s", sub_err[k]);
+    }
+    rt_render_stats st = sub_stats[0];
+    for (int k = 1; k < n_sub; ++k) {
+        const rt_render_stats& s = sub_stats[k];
+        st.primary_rays += s.primary_rays; st.secondary_rays += s.secondary_rays; st.shadow_rays += s.shadow_rays; st.rays += s.rays;
+        st.levels = std::max(st.levels, s.levels);
+        st.ms_closest += s.ms_closest; st.ms_shadow += s.ms_shadow; st.ms_shade += s.ms_shade;
+        st.ms_total = std::max(st.ms_total, s.ms_total);
+        st.launches_closest += s.launches_closest; st.launches_shadow += s.launches_shadow; st.launches_shade += s.launches_shade;
+        st.timed_closest_rays += s.timed_closest_rays; st.timed_shadow_rays += s.timed_shadow_rays;
     }
     if (mem == RT_MEM_HOST) {
         const int bands = (c->height + 7) / 8;
@@ -1611,24 +1788,11 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             const size_t off = row0 * c->width * 3, cnt = rows * c->width * 3;
             HIP_TRY(hipMemcpyAsync(out_rgb + off, d_out + off, cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
         }
+        HIP_TRY(hipStreamSynchronize(stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
     if (a->collect_stats) {
         if (int rc = stats_end(a, stream)) return rc;
     }
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ev_total[0], ev_total[1]));
-    st.ms_total = ms;
-    for (int k = 0; k + 1 < n_marks; ++k) {
-        if (mark_cls[k] == CLS_OTHER) continue;
-        HIP_TRY(hipEventElapsedTime(&ms, ev_mark[k], ev_mark[k + 1]));
-        if (mark_cls[k] == CLS_CLOSEST) st.ms_closest += ms;
-        else if (mark_cls[k] == CLS_SHADOW) st.ms_shadow += ms;
-        else st.ms_shade += ms;
-    }
-    st.secondary_rays = a->h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
-    st.shadow_rays = a->h_totals->shadow_rays;
-    st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
     a->q.search_calls += st.rays;
     a->q.closest_rays += st.primary_rays + st.secondary_rays;
     a->q.any_rays += st.shadow_rays;
@@ -1648,11 +1812,12 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     if (int rc = frame_params(a, c, F, n0)) return rc;
     if (c->band_world != 1) return fail(RT_ERR_UNSUPPORTED, "rt_render_primary_hits renders the whole image");
     hipStream_t stream = (hipStream_t)stream_;
-    if (a->levels.empty()) a->levels.resize(1);
-    Level& lv = a->levels[0];
+    FrameCtx& x = a->frame[0];
+    if (x.levels.empty()) x.levels.resize(1);
+    Level& lv = x.levels[0];
     HIP_TRY(lv.reserve(n0, false));
-    HIP_TRY(a->d_counters.reserve(CNT_WORDS));
-    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(256), 0, stream, a->d_counters.p, 1u, (LevelSlot*)nullptr, 0u, (FrameTotals*)nullptr);
+    HIP_TRY(x.d_counters.reserve(CNT_WORDS));
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(256), 0, stream, x.d_counters.p, 1u, (LevelSlot*)nullptr, 0u, (FrameTotals*)nullptr);
     HIP_TRY(hipGetLastError());
     const size_t npix = (size_t)c->width * c->height;
     float* d_t = out_t;
@@ -1667,7 +1832,7 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     const uint32_t sparse_c = pool_sparse(a, mode_c, n0, 1);
     const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0, sparse_c) + block_c.x - 1) / block_c.x));
     launch_closest(F.cull != 0, mode_c, grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0,
-                   lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, a->d_counters.p, launch_opts(a, sparse_c));
+                   lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, x.d_counters.p, launch_opts(a, sparse_c));
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);
     HIP_TRY(hipGetLastError());
