@@ -159,7 +159,8 @@ int rt_ads_search(rt_ads* ads, const float* rays, uint64_t n, uint64_t* out_offs
  * Limits: n <= RT_SEARCH_NOALLOC_MAX_RAYS and n * (octree nodes) * 8 bytes <= RT_SEARCH_NOALLOC_SCRATCH_BYTES,
  * otherwise RT_ERR_CAPACITY and nothing is launched.  *out_total receives the total list length; if it exceeds cap,
  * the entries at positions >= cap are not written (the caller checks *out_total after synchronising).  All calls on
- * one GPU share the scratch array: calls that overlap on a GPU (different streams or handles) race. */
+ * one GPU share the scratch array: calls that overlap on a GPU (different streams or handles) race.  The call is not
+ * counted in rt_query_stats (it brings nothing back to the host; the counters of Octree::PrintStats are rt_ads_search's). */
 #define RT_SEARCH_NOALLOC_MAX_RAYS 4096u
 #define RT_SEARCH_NOALLOC_SCRATCH_BYTES (16u << 20)
 int rt_ads_search_noalloc(rt_ads* ads, const float* rays, uint64_t n, uint64_t* out_offsets, uint32_t* out_tri, uint64_t cap,

@@ -1081,7 +1081,7 @@ int rt_ads_search(rt_ads* a, const float* rays, uint64_t n, uint64_t* out_offset
     // through to the exact two-pass form below.
     constexpr uint64_t kRegion = 1024, kSmallBatch = 64;
     bool done = false;
-    if (n <= kSmallBatch) {
+    if (n <= std::min<uint64_t>(kSmallBatch, chunk)) {  // (the workspace holds the rays and queues of `chunk` rays)
         const uint32_t m = (uint32_t)n;
         const size_t words = (size_t)m * 2 + (size_t)m * kRegion;  // m 64-bit counts, then m regions
         HIP_TRY(ws.out.reserve(words));
@@ -1200,7 +1200,7 @@ int rt_ads_search_noalloc(rt_ads* a, const float* rays, uint64_t n, uint64_t* ou
                            (const uint64_t*)out_offsets, out_tri, cap, (uint64_t)0, (unsigned long long*)nullptr);
         HIP_TRY(hipGetLastError());
     }
-    a->q.search_calls += n;
+    // (no query counter is touched: the call is asynchronous and brings no totals back to the host)
     return RT_OK;
 }
 

@@ -285,6 +285,10 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counters, bool want, 
         // The sums go in with returning atomics whose results are consumed before the ticket is taken: a returned atomic
         // has been performed at the level where all XCDs see it, so no fence is needed between sums and ticket (an
         // agent-scope fence writes back the whole L2 of the XCD -- per block, that costs more than the traversal).
+        // This leans on the hardware, not on the memory model: device-scope atomics of gfx942 / gfx950 are executed at
+        // the memory side of the fabric, in issue order per address, and the empty asm below keeps the compiler from
+        // moving the ticket above the sums.  A stale total would show at once: the host sizes the next launches from
+        // these numbers and every frame's ray counts are compared with the oracle's in the tests.
         const uint32_t r0 = atomicAdd(&counters[CNT_WORK], total);
         s_base = r0;
         const unsigned long long r1 = atomicAdd((unsigned long long*)&counters[CNT_SHADOW_LO], (unsigned long long)wsum);
@@ -601,6 +605,16 @@ __global__ void __launch_bounds__(256) k_stats_shadow(SceneDev S, FrameParams F,
     stats_flush<true>(c, totals);
 }
 
+// pow(x, y) of the specular terms (renderer.cc:263,283) for x >= 0 (a clamped cosine) or NaN: exp2(y * log2(x)) on the
+// transcendental unit -- 4 instructions where the library's correctly rounded powf is some 80.  The device's powf is not
+// the reference's libm either; shaded colours are compared within 1/255, and this form stays within about
+// |y| * 2^-21 relative of the exact power.  The special cases that the formula would get wrong are pow(x, 0) = 1 for
+// every x (0 * -inf and NaN included) and pow(1, y) = 1; pow(0, y > 0) = 0 and pow(NaN, y != 0) = NaN come out of it.
+__device__ __forceinline__ float shade_pow(float x, float y) {
+    const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    return (y == 0.0f || x == 1.0f) ? 1.0f : r;
+}
+
 // Local illumination + recursion gate + secondary ray construction for every hit of one level
 // (renderer.cc:144-192, 202-335); the visibility of each light sample comes from k_shadow.
 __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
@@ -634,7 +648,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
 
     // The specular term is (I_l * specular) * pow(base, shininess).  With an all-zero specular colour and a
     // non-negative shininess the power is finite, so the product is the same zero (or the NaN that I_l already is)
-    // whatever the power's value: a wave none of whose lanes has a specular material skips powf and the two
+    // whatever the power's value: a wave none of whose lanes has a specular material skips the power and the two
     // normalisations that only feed it.
     const bool spec_is_zero = specular.x == 0.0f && specular.y == 0.0f && specular.z == 0.0f && m.shininess >= 0.0f;
     const bool wave_needs_pow = ballot64(valid && !spec_is_zero) != 0;
@@ -675,10 +689,10 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
                     const f3 d_v = normalize(F.cam_pos - P);
                     if (F.render_type == 2) {  // renderer.cc:256-263
                         const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
-                        pw = powf(std_max(0.0f, dot(d_v, d_r)), m.shininess);
+                        pw = shade_pow(std_max(0.0f, dot(d_v, d_r)), m.shininess);
                     } else {  // renderer.cc:276-283
                         const f3 d_h = normalize(d_l + d_v);
-                        pw = powf(std_max(0.0f, dot(N, d_h)), m.shininess);
+                        pw = shade_pow(std_max(0.0f, dot(N, d_h)), m.shininess);
                     }
                 }
                 const f3 I_s = (I_l * specular) * pw;

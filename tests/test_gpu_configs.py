@@ -162,6 +162,14 @@ def test_large_tree_4k_frame_properties(rt, orc, monkeypatch):
         img, st = g.render(cfg)
         frames[form] = (img, st.rays, st.shadow_rays, st.secondary_rays)
         if form == "auto":
+            # Ads::Search on a tree so big (533,107 nodes) that the queues of 64 rays exceed the call's workspace: the
+            # batch is walked in chunks, every list equals the single-ray call's and the oracle's candidate order
+            rng = np.random.default_rng(5)
+            rays = np.concatenate([rng.uniform(50, 500, (64, 3)), rng.normal(size=(64, 3))], axis=1).astype(np.float32)
+            lists = g.search_batch(rays)
+            for i in (0, 17, 62, 63):
+                assert np.array_equal(lists[i], g.search_batch(rays[i:i + 1])[0]), i
+            assert sum(len(x) for x in lists) > 64
             # two ranks' bands reassemble to the same frame
             out = np.zeros_like(img)
             rays = 0
