@@ -22,7 +22,10 @@ a sample) -- a reference-equivalent rate; `executed_lane_ops_per_launch` / `valu
 the kernel really issues (VALU instruction counters of a rocprofv3 pass, committed under profiles/).
 `cpu_baseline` is the CPU restatement on one host core, `cpu_baseline_all_cores` the same on all
 cores of this box (threads over image rows), `cpu_baseline_reference` the unmodified reference binary.
-`other_workloads` carries a few frames of the other single-GPU benchmark configurations.
+`other_workloads` carries a few frames of the other benchmark configurations: with one GPU all of them, each with its
+own one-core `cpu_baseline` on a few rows of its frame; with N > 1 the two the scaling target is stated on (the
+1.31 M-triangle scene and the 4K fuzzysampling frame), band-split over the ranks like the main workload, gather included,
+with the pipelined rate and the un-overlapped latency (first launch -> frame resident on rank 0) side by side.
 """
 import argparse
 import json
@@ -49,7 +52,7 @@ WORKLOADS = {
     # 1,310,754 triangles (Cornell box + icosphere level 8), hard shadows, true aspect ratio
     "synthetic_ico8_phong_4k": dict(
         scene="synthetic:8", cam=CAM_ORIGINAL, width=3840, height=2160, spp=1, spt=1, render_type="phong",
-        shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160)),
+        shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160), streams=4),
     # fuzzysampling (64 samples per pixel) + 32 samples per light, 4K
     "cornell_original_blinn_spp64_spt32_4k": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong",
@@ -59,9 +62,13 @@ WORKLOADS = {
         scene="cornell_original", cam=CAM_ORIGINAL, width=256, height=256, spp=1, spt=4, render_type="blinn_phong",
         shading="flat", cull=True, max_depth=10, cpu_rows=(96, 160)),
 }
+# "streams": sub-frames a rt_render call of the workload runs concurrently (rt_ads_set_render_streams); pays where a frame
+# is a long chain of small recursion levels
 DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
 # frames of the other configurations that the default single-GPU run appends to its line
 OTHER_WORKLOADS = {"cornell_sphere_blinn_smooth_spp4_1080p": 4, "synthetic_ico8_phong_4k": 5, "cornell_original_blinn_spp64_spt32_4k": 2}
+# ... and the ones a multi-GPU run appends (band-split over the ranks): the workloads the scaling target names
+OTHER_WORKLOADS_MULTI = {"synthetic_ico8_phong_4k": 6, "cornell_original_blinn_spp64_spt32_4k": 2}
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 FP32_NO_FMA_PEAK_TOPS = 78.6      # the same lanes issuing one non-fused op per clock (bit-parity forbids FMA)
@@ -165,7 +172,7 @@ def pmc_file():
     import glob
     override = os.environ.get("RT_BENCH_COUNTERS")
     if override and os.path.exists(override):
-        return override, "profiles/" + os.path.basename(override)
+        return override, os.path.relpath(os.path.abspath(override), ROOT) + " (collected on this box just before this run; not a committed file)"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
     return (files[-1], "profiles/" + os.path.basename(files[-1])) if files else (None, None)
 
@@ -194,36 +201,174 @@ def memory_side(kernels, name, workload):
         kernels[k]["counters_source"] = src
 
 
-def run_other_workload(name, frames, rt, Scene, torch):
-    """A few frames of another benchmark configuration on this GPU (device-resident frame buffer, one rank)."""
-    wl = WORKLOADS[name]
-    scene = load_scene(wl, Scene)
-    ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+def build_ads(rt, scene, wl, device=0):
+    ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=device)
     ads.Build(scene.pos)
     ads.set_shading(scene.norm, scene.matid, scene.materials)
-    cfg = rt.make_render_config(**render_kwargs(wl))
-    frame = torch.zeros((wl["height"] + 8, wl["width"], 3), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
-    torch.cuda.synchronize()
+    ads.set_render_streams(int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)))
+    return ads
+
+
+class FrameLoop:
+    """Renders frames of one workload on this rank's bands and moves them to rank 0.
+
+    Two frame buffers: while the bands of one frame travel to rank 0 (RCCL, on its own stream), the next frame is
+    rendered into the other buffer.  overlap=False completes every gather before the next frame starts.  The gathers
+    run on a worker thread with its own stream (use_thread=False: on the calling thread, between the frames): the
+    renderer's call only returns when its frame is complete, so whatever the calling thread does between two calls --
+    the host side of the collective included -- would otherwise add to every frame."""
+
+    def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True):
+        from raytracer_amd import distributed as rd
+        self.ads, self.torch, self.dist = ads, torch, dist
+        self.H, self.W = wl["height"], wl["width"]
+        self.cfg = rt.make_render_config(band_rank=rank, band_world=world, **render_kwargs(wl))
+        self.frames = [rd.alloc_frame(self.H, self.W, world, "cuda") for _ in range(2)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.gathers = [rd.BandGather(self.H, self.W, rank, world, "cuda", dist) for _ in range(2)]
+        self.overlap = dist is not None and overlap
+        self.worker = rd.GatherThread(self.frames, self.gathers) if self.overlap and use_thread else None
+        self.n = 0
+
+    def step(self):
+        k = self.n & 1
+        self.n += 1
+        if self.worker is not None:
+            self.worker.wait(k)  # this buffer's previous frame must have arrived before it is overwritten
+            _, st = self.ads.render(self.cfg, out_ptr=self.frames[k].data_ptr(), stream=self.stream)
+            self.worker.submit(k)  # framebuffer bands -> rank 0
+            return st
+        self.gathers[k].finish()
+        _, st = self.ads.render(self.cfg, out_ptr=self.frames[k].data_ptr(), stream=self.stream)
+        self.gathers[k].start(self.frames[k])  # no-op for one rank
+        if not self.overlap:
+            self.gathers[k].finish()
+        return st
+
+    def fence(self):
+        if self.worker is not None:
+            self.worker.wait()
+        for g_ in self.gathers:
+            g_.finish()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, acc=None):
+        """Seconds for `steps` frames between two fences (barrier + device synchronisation on both sides)."""
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = self.step()
+            if acc is not None:
+                add_stats(acc, st)
+        self.fence()
+        return time.perf_counter() - t0
+
+    def last_frame(self):
+        return self.frames[(self.n - 1) & 1]
+
+    def close(self):
+        if self.worker is not None:
+            self.worker.close()
+            self.worker = None
+
+
+def max_over_ranks(seconds, dist, torch):
+    if dist is None:
+        return seconds
+    tt = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def sum_over_ranks(count, dist, torch):
+    if dist is None:
+        return count
+    rr = torch.tensor([count], dtype=torch.int64, device="cuda")
+    dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+    return int(rr.item())
+
+
+def cpu_sample(wl, scene, frame_rows=None):
+    """The CPU restatement (oracle/rt_oracle.c, one host core) on the workload's cpu_rows: its rate, and -- if the
+    device frame's rows are given -- the largest difference between the two on those rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as orc
+    osc = orc.Scene.from_arrays(scene.pos, scene.norm, scene.matid, scene.materials)
+    b0 = time.perf_counter()
+    otree = orc.Octree(osc, 16, 10)
+    build_s = time.perf_counter() - b0
+    r0, r1 = wl["cpu_rows"]
+    ocfg = orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(r0, r1), **render_kwargs(wl))
+    c0 = time.perf_counter()
+    ref, _, _, ost = orc.render(osc, otree, ocfg, want_hits=False)
+    cpu_s = time.perf_counter() - c0
+    out = {"value": ost.search_calls / cpu_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+           "sample": f"rows {r0}..{r1 - 1} of the same frame ({ost.search_calls} rays, {cpu_s:.1f} s; octree built in {build_s:.1f} s, not "
+                     "counted), oracle/rt_oracle.c -O2, counter RNG"}
+    parity = None
+    if frame_rows is not None:
+        diff = float(np.abs(frame_rows - ref[r0:r1]).max())
+        parity = {"max_abs_diff": diff, "tolerance": 1.0 / 255.0, "ok": diff <= 1.0 / 255.0}
+    return out, parity, (osc, otree, ost, orc)
+
+
+def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=None, cpu=True):
+    """A few frames of another benchmark configuration (device-resident frame buffer): on one GPU with its kernel-class
+    rates, reference work and a one-core CPU sample; on N ranks band-split with the gather, pipelined and un-overlapped."""
+    wl = WORKLOADS[name]
+    scene = load_scene(wl, Scene)
+    ads = build_ads(rt, scene, wl, device=torch.cuda.current_device())
+    loop = FrameLoop(ads, rt, wl, rank, world, dist, torch)
+    loop.step()
     acc = new_acc()
-    t0 = time.perf_counter()
-    for _ in range(frames):
-        _, st = ads.render(cfg, out_ptr=frame.data_ptr(), stream=stream)
-        add_stats(acc, st)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    work = reference_work(ads, rt, wl)
+    elapsed = max_over_ranks(loop.timed(frames, acc), dist, torch)
+    rays = sum_over_ranks(acc["rays"], dist, torch)
+    loop.close()
     ts = ads.tree_stats()
-    ks = kernel_summary(acc, frames, work)
-    memory_side(ks, name, name)
-    res = {"Mrays_per_s": acc["rays"] / elapsed / 1e6, "ms_per_frame": elapsed / frames * 1e3, "frames": frames,
-           "rays_per_frame": acc["rays"] // frames, "triangles": scene.n_triangles, "octree_nodes": ts["nodes"],
-           "octree_build_s": round(ts["build_seconds"], 4), "reference_work_per_ray": work, "kernels": ks,
-           "k_shadow_frac": ks["k_shadow"].get("frac_of_fp32_vector_peak"), "k_closest_frac": ks["k_closest"].get("frac_of_fp32_vector_peak"),
-           "k_shadow_hbm_frac": ks["k_shadow"].get("hbm_frac")}
+    res = {"Mrays_per_s": rays / elapsed / 1e6, "ms_per_frame": elapsed / frames * 1e3, "frames": frames,
+           "rays_per_frame": rays // frames, "triangles": scene.n_triangles, "octree_nodes": ts["nodes"],
+           "octree_build_s": round(ts["build_seconds"], 4), "render_streams": int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)),
+           "n_gpus": world}
+    if dist is not None:
+        # the same frames one after the other: rendering, gather and interleaving copy of a frame complete before the next
+        # one starts -- the latency from the first launch to the frame resident on rank 0
+        sync = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=False)
+        sync.step()
+        n_sync = max(2, frames // 2)
+        res["unoverlapped_ms_per_frame"] = max_over_ranks(sync.timed(n_sync), dist, torch) / n_sync * 1e3
+        res["pipelined_ms_per_frame"] = res["ms_per_frame"]
+        sync.close()
+    else:
+        # kernel-class times: with concurrent sub-frames the launches of a class overlap one another, so the classes
+        # are timed on frames rendered as one piece
+        if res["render_streams"] > 1:
+            ads.set_render_streams(1)
+            one = FrameLoop(ads, rt, wl, rank, world, dist, torch)
+            one.step()
+            acc = new_acc()
+            n_one = max(2, frames // 2)
+            res["ms_per_frame_one_stream"] = one.timed(n_one, acc) / n_one * 1e3
+            frames_k = n_one
+            one.close()
+        else:
+            frames_k = frames
+        work = reference_work(ads, rt, wl)
+        ks = kernel_summary(acc, frames_k, work)
+        memory_side(ks, name, name)
+        res.update({"reference_work_per_ray": work, "kernels": ks,
+                    "k_shadow_frac": ks["k_shadow"].get("frac_of_fp32_vector_peak"), "k_closest_frac": ks["k_closest"].get("frac_of_fp32_vector_peak"),
+                    "k_shadow_hbm_frac": ks["k_shadow"].get("hbm_frac")})
+        if cpu:
+            r0, r1 = wl["cpu_rows"]
+            rows = loop.last_frame()[r0:r1].cpu().numpy()
+            res["cpu_baseline"], res["parity_on_sample"], _ = cpu_sample(wl, scene, rows)
+            res["gpu_over_cpu_one_core"] = res["Mrays_per_s"] / res["cpu_baseline"]["value"]
     ads.close()
-    del frame
+    del loop
     return res
 
 
@@ -295,73 +440,37 @@ def main():
 
     wl = WORKLOADS[args.workload]
     scene = load_scene(wl, Scene)
-    ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=local_rank)
-    ads.Build(scene.pos)
-    ads.set_shading(scene.norm, scene.matid, scene.materials)
+    ads = build_ads(rt, scene, wl, device=local_rank)
     tree_stats = ads.tree_stats()
     W, H = wl["width"], wl["height"]
     kw = render_kwargs(wl)
     aspect = kw["aspect_mode"]
     cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
 
-    from raytracer_amd import distributed as rd
-    # Two frame buffers: while the bands of one frame travel to rank 0 (RCCL, on its own stream), the next frame is
-    # rendered into the other buffer.  RT_BENCH_SYNC_GATHER=1 completes every gather before the next frame starts.
-    frames = [rd.alloc_frame(H, W, world, "cuda") for _ in range(2)]
-    frame = frames[0]
-    stream = torch.cuda.current_stream().cuda_stream
-    gathers = [rd.BandGather(H, W, rank, world, "cuda", dist) for _ in range(2)]
-    overlap = dist is not None and os.environ.get("RT_BENCH_SYNC_GATHER") != "1"
-    # The gathers run on a worker thread with its own stream (RT_BENCH_GATHER_THREAD=0: on this thread, between the
-    # frames): the renderer's call only returns when its frame is complete, so whatever this thread does between two
-    # calls -- the host side of the collective included -- would otherwise add to every frame.
-    worker = rd.GatherThread(frames, gathers) if overlap and os.environ.get("RT_BENCH_GATHER_THREAD") != "0" else None
-    step_no = [0]
-
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if worker is not None:
-            worker.wait(k)  # this buffer's previous frame must have arrived before it is overwritten
-            _, st = ads.render(cfg, out_ptr=frames[k].data_ptr(), stream=stream)
-            worker.submit(k)  # framebuffer bands -> rank 0
-            return st
-        gathers[k].finish()
-        _, st = ads.render(cfg, out_ptr=frames[k].data_ptr(), stream=stream)
-        gathers[k].start(frames[k])  # no-op for one rank
-        if not overlap:
-            gathers[k].finish()
-        return st
-
-    def fence():
-        if worker is not None:
-            worker.wait()
-        for g_ in gathers:
-            g_.finish()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    loop = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=os.environ.get("RT_BENCH_SYNC_GATHER") != "1",
+                     use_thread=os.environ.get("RT_BENCH_GATHER_THREAD") != "0")
     for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
+        loop.step()
     acc = new_acc()
-    for _ in range(args.steps):
-        add_stats(acc, step())
-    fence()
-    elapsed = time.perf_counter() - t0
-    if worker is not None:
-        worker.close()
-    rays = acc["rays"]
+    elapsed = max_over_ranks(loop.timed(args.steps, acc), dist, torch)
+    rays = sum_over_ranks(acc["rays"], dist, torch)
+    frame = loop.last_frame()
+    loop.close()
+    unoverlapped_ms = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([rays], dtype=torch.int64, device="cuda")
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays = int(rr.item())
+        sync = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=False)
+        sync.step()
+        n_sync = max(2, min(args.steps, 10))
+        unoverlapped_ms = max_over_ranks(sync.timed(n_sync), dist, torch) / n_sync * 1e3
+        sync.close()
+
+    others_multi = None
+    # (RT_BENCH_FORCE_DIST=1 RT_BENCH_MULTI_OTHERS=1 runs this path with a single rank: a check of it on a one-GPU box)
+    multi = world > 1 or os.environ.get("RT_BENCH_MULTI_OTHERS") == "1"
+    if dist is not None and multi and not args.no_extras and not args.no_other_workloads and args.workload == DEFAULT_WORKLOAD:
+        # every rank takes part: the frames are band-split and gathered like the main workload's
+        others_multi = {name: run_other_workload(name, n_frames, rt, Scene, torch, rank, world, dist, cpu=False)
+                        for name, n_frames in OTHER_WORKLOADS_MULTI.items()}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -379,6 +488,12 @@ def main():
                        "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3),
                        "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)"},
         }
+        if unoverlapped_ms is not None:
+            # `value` is the pipelined rate (the gather of a frame overlaps the rendering of the next); this is one frame
+            # from its first launch to the framebuffer resident on rank 0, nothing overlapped
+            out["frame_latency"] = {"pipelined_ms_per_frame": ms_per_step, "unoverlapped_ms_per_frame": unoverlapped_ms,
+                                    "note": "un-overlapped: rendering, RCCL gather of the bands and the interleaving copy of a frame "
+                                            "complete before the next frame starts"}
         work = None
         if world == 1 and not args.no_extras:
             # reference work per ray, counted on the device in the reference's definitions (whole reduced frame)
@@ -386,23 +501,10 @@ def main():
             out["reference_work_per_ray"] = work
         # ---- CPU baselines on bounded samples of the same frame (rank 0, N = 1 only) ----
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as orc
-            osc = orc.Scene.from_arrays(scene.pos, scene.norm, scene.matid, scene.materials)
-            otree = orc.Octree(osc, 16, 10)
             r0, r1 = wl["cpu_rows"]
             okw = {k: v for k, v in kw.items()}
-            ocfg = orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(r0, r1), **okw)
-            c0 = time.perf_counter()
-            ref, _, _, ost = orc.render(osc, otree, ocfg, want_hits=False)
-            cpu_s = time.perf_counter() - c0
-            img = frame[:H].cpu().numpy()
-            diff = float(np.abs(img[r0:r1] - ref[r0:r1]).max())
             model = cpu_model()
-            out["cpu_baseline"] = {"value": ost.search_calls / cpu_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "cpu": model,
-                                   "sample": f"rows {r0}..{r1 - 1} of the same frame ({ost.search_calls} rays, {cpu_s:.1f} s), "
-                                             "oracle/rt_oracle.c -O2, counter RNG"}
-            out["parity_on_sample"] = {"max_abs_diff": diff, "tolerance": 1.0 / 255.0, "ok": diff <= 1.0 / 255.0}
+            out["cpu_baseline"], out["parity_on_sample"], (osc, otree, ost, orc) = cpu_sample(wl, scene, frame[r0:r1].cpu().numpy())
             # the CPU restatement's own count of the reference work on the sampled rows: cross-check of the device counters
             n_any = max(ost.shadow_rays, 1)
             n_closest = max(ost.primary_rays + ost.secondary_rays, 1)
@@ -491,7 +593,7 @@ def main():
                     roof["executed_valu_insts_per_launch"] = k.get("SQ_INSTS_VALU")
                     roof["executed_salu_insts_per_launch"] = k.get("SQ_INSTS_SALU")
                     roof["valu_issue_frac"] = k["valu_lane_ops_per_launch"] / (sh["avg_launch_ms"] * 1e-3) / 1e12 / FP32_NO_FMA_PEAK_TOPS
-                    roof["valu_busy_frac_profiled"] = k.get("valu_busy_frac")
+                    roof["lanes_active_per_valu_inst"] = k.get("lanes_active")
                     roof["lds_bank_conflict_frac"] = k.get("lds_bank_conflict_frac")
                     roof["counters_source"] = src + " (rocprofv3 --pmc SQ_* passes, per-launch means; valu_issue_frac divides the executed wave64 " \
                                                     "VALU lane-ops by this run's kernel time and the 78.6 T lane-ops/s issue peak)"
@@ -499,8 +601,10 @@ def main():
         if world == 1 and not args.no_extras and not args.no_other_workloads and args.workload == DEFAULT_WORKLOAD:
             others = {}
             for name, n_frames in OTHER_WORKLOADS.items():
-                others[name] = run_other_workload(name, n_frames, rt, Scene, torch)
+                others[name] = run_other_workload(name, n_frames, rt, Scene, torch, cpu=not args.no_cpu_baseline)
             out["other_workloads"] = others
+        if others_multi is not None:
+            out["other_workloads"] = others_multi
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

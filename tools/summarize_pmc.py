@@ -34,7 +34,9 @@ def main():
                        "--no-cpu-baseline --no-extras --workload <w>, one MI355X.  Every value is the mean over the launches of that "
                        "kernel class in the run (all recursion levels; 'largest' = the level-0 launch).  Derived: "
                        "valu_lane_ops_per_launch = SQ_INSTS_VALU x 64 (a wave64 instruction occupies 64 lanes whatever its exec mask); "
-                       "salu_per_valu = SQ_INSTS_SALU / SQ_INSTS_VALU; valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / GRBM_GUI_ACTIVE; "
+                       "salu_per_valu = SQ_INSTS_SALU / SQ_INSTS_VALU; lanes_active = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU ... per 64; "
+                       "(no VALU-busy fraction is derived from SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE: the latter is summed over the 8 XCDs and the "
+                       "former's unit could not be pinned on this chip -- the figure to read is valu_issue_frac, executed instructions over kernel time); "
                        "wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
                        "l2_hit_rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); bytes_per_launch = 2 x 1024 x FETCH_SIZE (gfx950 tallies "
                        "128-B read requests at 64 B) + 1024 x WRITE_SIZE.",
@@ -57,8 +59,8 @@ def main():
                 e["largest_launch_valu_lane_ops"] = max(d["SQ_INSTS_VALU"]) * 64.0
                 if e.get("SQ_INSTS_SALU") is not None and e["SQ_INSTS_VALU"]:
                     e["salu_per_valu"] = e["SQ_INSTS_SALU"] / e["SQ_INSTS_VALU"]
-                if e.get("GRBM_GUI_ACTIVE"):
-                    e["valu_busy_frac"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / N_SIMD / e["GRBM_GUI_ACTIVE"]
+                if e.get("SQ_THREAD_CYCLES_VALU") and e.get("SQ_ACTIVE_INST_VALU"):
+                    e["lanes_active"] = e["SQ_THREAD_CYCLES_VALU"] / e["SQ_ACTIVE_INST_VALU"]
                 if e.get("SQ_WAVE_CYCLES"):
                     e["wait_inst_frac"] = e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]
                 if e.get("SQ_WAVES"):
@@ -82,7 +84,7 @@ def main():
         for k in ("k_shadow", "k_closest"):
             e = d["kernels"].get(k, {})
             print(wl, k, {c: (round(v, 4) if isinstance(v, float) and v < 10 else v) for c, v in e.items() if c in (
-                "launches", "valu_lane_ops_per_launch", "salu_per_valu", "valu_busy_frac", "wait_inst_frac", "lds_bank_conflict_frac", "l2_hit_rate", "bytes_per_launch", "valu_insts_per_wave")})
+                "launches", "valu_lane_ops_per_launch", "salu_per_valu", "lanes_active", "wait_inst_frac", "lds_bank_conflict_frac", "l2_hit_rate", "bytes_per_launch", "valu_insts_per_wave")})
 
 
 if __name__ == "__main__":
