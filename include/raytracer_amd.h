@@ -287,6 +287,15 @@ int rt_scene_data_export(const rt_scene_data* s, float* positions, float* normal
 /* Renderer::save_image_to_pmm + write_color (src/Renderer/renderer.cc:381-390, src/color.h:12-15): P3 text. */
 int rt_write_ppm(const char* path, int32_t width, int32_t height, const float* rgb);
 
+/* Diagnostics for tests: every (ray, triangle) pair through the three forms in which the kernels evaluate
+ * collision_ray_triangle (src/collision_detection.h:12-68) -- the compiled form and the two hand-scheduled any-hit forms
+ * (triangle in scalar registers / per lane) -- so that a test can compare the distances they compute bit for bit.
+ * origins, dirs: n_rays x 3 floats (unit-length or zero directions: the hand-scheduled forms' precondition);
+ * positions: n_triangles x 9 floats; out: 3 x n_rays x n_triangles floats, form-major, +inf = no usable hit
+ * (t == infinity || t < epsilon, renderer.cc:126). */
+int rt_debug_triangle_tests(int device, const float* origins, const float* dirs, uint32_t n_rays, const float* positions,
+                            uint32_t n_triangles, int cull_backfaces, float* out);
+
 const char* rt_last_error(void);
 /* Library / device identification, for logs. */
 const char* rt_version(void);

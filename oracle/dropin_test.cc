@@ -2,9 +2,14 @@
 // exists) together with the reference's own Octree sources and linked against libraytracer_amd.so:
 // it instantiates the reference's `Octree` and this build's `GpuOctree` (raytracer_amd/host/gpu_octree_ads.h)
 // behind the reference's `Ads` interface, feeds both the same triangles and rays, and requires
-//   * Search() to return the same shared_ptr<const Triangle> sequence, element for element, and
+//   * Search() to return the same shared_ptr<const Triangle> sequence, element for element,
+//   * PrintStats() of the two, after those identical Search calls, to print the same text line for line
+//     (octree.cc:211-223; the "Search time" line, a wall-clock figure, excepted),
 //   * the reference's closest-hit loop over its candidates (renderer.cc:123-134) to agree with the
-//     batched TraceClosest on the winning triangle and on t bit for bit.
+//     batched TraceClosest on the winning triangle and on t bit for bit, and
+//   * the reference's any-hit loop (Renderer::is_shadowed, renderer.cc:288-313, restated over the reference's
+//     own Search and collision_ray_triangle) to agree with the batched TraceAny on every flag, with and
+//     without back-face culling; the segments start ON the surfaces the closest hits found, like the renderer's.
 // Usage: ads_dropin_test <scene.raw> [n_rays]      scene.raw = uint64 n, then n*9 float32 positions.
 #include <cstdint>
 #include <cstdio>
@@ -12,6 +17,8 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "include/json.hpp"
@@ -112,6 +119,33 @@ int main(int argc, char** argv) {
             origins.insert(origins.end(), {o.x, o.y, o.z});
             dirs.insert(dirs.end(), {d.x, d.y, d.z});
         }
+        // PrintStats after identical Search calls (octree.cc:209-224): the same text, the wall-clock line aside
+        {
+            std::ostringstream sa, sb;
+            ref->PrintStats(sa);
+            gpu->PrintStats(sb);
+            std::istringstream ia(sa.str()), ib(sb.str());
+            std::string la, lb;
+            int lines = 0;
+            for (;;) {
+                const bool ga = (bool)std::getline(ia, la), gb = (bool)std::getline(ib, lb);
+                if (ga != gb) {
+                    std::cerr << "PrintStats: different number of lines\n";
+                    return 1;
+                }
+                if (!ga) break;
+                ++lines;
+                if (la.rfind("  Search time:", 0) == 0 && lb.rfind("  Search time:", 0) == 0) continue;
+                if (la != lb) {
+                    std::cerr << "PrintStats line " << lines << ": reference '" << la << "' vs '" << lb << "'\n";
+                    return 1;
+                }
+            }
+            if (lines != 13) {
+                std::cerr << "PrintStats: " << lines << " lines, expected 13\n";
+                return 1;
+            }
+        }
         std::vector<float> t(n_rays);
         std::vector<int32_t> tri(n_rays);
         static_cast<GpuOctree*>(gpu.get())->TraceClosest(origins.data(), dirs.data(), (uint64_t)n_rays, true, t.data(), tri.data());
@@ -123,8 +157,50 @@ int main(int argc, char** argv) {
             }
             hits += tri[r] >= 0;
         }
+        // Renderer::is_shadowed (renderer.cc:288-313) over the reference's Search, against the batched TraceAny.
+        // Surface points: where the closest hits landed (renderer.cc:146: origin + direction * t, no offset).
+        uint64_t any_pairs = 0, any_shadowed = 0;
+        for (int cull = 1; cull >= 0; --cull) {
+            std::vector<float> points, lights;
+            std::vector<uint8_t> want;
+            for (int r = 0; r < n_rays; ++r) {
+                if (ref_tri[r] < 0) continue;
+                const Vec3 o(origins[r * 3], origins[r * 3 + 1], origins[r * 3 + 2]), d(dirs[r * 3], dirs[r * 3 + 1], dirs[r * 3 + 2]);
+                const Vec3 p = o + d * ref_t[r];
+                const Vec3 l(lo.x + (hi.x - lo.x) * unit(seed), lo.y + (hi.y - lo.y) * unit(seed), lo.z + (hi.z - lo.z) * unit(seed));
+                const float dist_light = (l - p).length();
+                Ray shadow_ray(p, (l - p).normalize());
+                auto cand = ref->Search(shadow_ray);
+                bool shadowed = false;
+                for (size_t k = 0; k < cand.size(); ++k) {
+                    const float st = collision_ray_triangle(shadow_ray, *cand[k], cull != 0);
+                    if (st == infinity || st < epsilon) continue;
+                    if (st < dist_light) {
+                        shadowed = true;
+                        break;
+                    }
+                }
+                points.insert(points.end(), {p.x, p.y, p.z});
+                lights.insert(lights.end(), {l.x, l.y, l.z});
+                want.push_back(shadowed ? 1 : 0);
+            }
+            std::vector<uint8_t> got(want.size());
+            static_cast<GpuOctree*>(gpu.get())->TraceAny(points.data(), lights.data(), (uint64_t)want.size(), cull != 0, got.data());
+            for (size_t k = 0; k < want.size(); ++k) {
+                if (got[k] != want[k]) {
+                    std::cerr << "segment " << k << " (cull " << cull << "): shadowed " << (int)got[k] << " vs reference " << (int)want[k] << "\n";
+                    return 1;
+                }
+                any_shadowed += want[k];
+            }
+            any_pairs += want.size();
+        }
+        if (any_pairs == 0 || any_shadowed == 0 || any_shadowed == any_pairs) {
+            std::cerr << "any-hit check is vacuous: " << any_shadowed << " of " << any_pairs << " segments shadowed\n";
+            return 1;
+        }
         gpu->PrintStats(std::clog);
-        std::cout << "DROPIN PASS rays=" << n_rays << " candidates=" << total << " hits=" << hits << std::endl;
+        std::cout << "DROPIN PASS rays=" << n_rays << " segments=" << any_pairs << " shadowed=" << any_shadowed << " candidates=" << total << " hits=" << hits << std::endl;
     } catch (std::exception& e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 1;

@@ -73,7 +73,7 @@ EXPORTS = [
     "rt_scene_set_shading", "rt_render", "rt_ads_set_render_streams", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
     "rt_host_tree_export_flat", "rt_host_tree_export_clustered", "rt_host_tree_stats",
-    "rt_scene_load_obj", "rt_scene_data_free", "rt_scene_data_sizes", "rt_scene_data_export", "rt_write_ppm",
+    "rt_debug_triangle_tests", "rt_scene_load_obj", "rt_scene_data_free", "rt_scene_data_sizes", "rt_scene_data_export", "rt_write_ppm",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def lib():
     L.rt_render.argtypes = [vp, C.POINTER(RenderConfig), vp, C.c_int, C.POINTER(RenderStats), vp]
     L.rt_render_primary_hits.argtypes = [vp, C.POINTER(RenderConfig), vp, vp, C.c_int, vp]
     L.rt_ads_set_render_streams.argtypes = [vp, C.c_int]
+    L.rt_debug_triangle_tests.argtypes = [C.c_int, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_int, vp]
     L.rt_host_tree_build.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rt_host_tree_destroy.argtypes = [vp]
     L.rt_host_tree_destroy.restype = None

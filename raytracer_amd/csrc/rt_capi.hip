@@ -1310,6 +1310,41 @@ int rt_ads_trace_any(rt_ads* a, const float* points, const float* lights, uint64
     return RT_OK;
 }
 
+int rt_debug_triangle_tests(int device, const float* origins, const float* dirs, uint32_t n_rays, const float* positions, uint32_t n_tris, int cull,
+                            float* out) {
+    if (!origins || !dirs || !positions || !out || !n_rays || !n_tris) return fail(RT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<LeafTri> g(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const float* p = positions + (size_t)i * 9;
+        LeafTri& s = g[i];
+        s.ax = p[0]; s.ay = p[1]; s.az = p[2];
+        s.e1x = p[3] - p[0]; s.e1y = p[4] - p[1]; s.e1z = p[5] - p[2];
+        s.e2x = p[6] - p[0]; s.e2y = p[7] - p[1]; s.e2z = p[8] - p[2];
+        s.tri = i;
+        s.pad0 = s.pad1 = 0;
+    }
+    DevBuf<float> d_o, d_d, d_out;
+    DevBuf<LeafTri> d_t;
+    const size_t n_out = (size_t)3 * n_rays * n_tris;
+    auto done = [&](int rc) {
+        d_o.release(); d_d.release(); d_out.release(); d_t.release();
+        return rc;
+    };
+    if (d_o.reserve((size_t)n_rays * 3) != hipSuccess || d_d.reserve((size_t)n_rays * 3) != hipSuccess || d_out.reserve(n_out) != hipSuccess ||
+        d_t.reserve(n_tris) != hipSuccess)
+        return done(fail(RT_ERR_HIP, "allocation failed"));
+    if (hipMemcpy(d_o.p, origins, (size_t)n_rays * 12, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_d.p, dirs, (size_t)n_rays * 12, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_t.p, g.data(), (size_t)n_tris * sizeof(LeafTri), hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(RT_ERR_HIP, "copy failed"));
+    const dim3 grid((n_rays + 255) / 256), block(256);
+    if (cull) hipLaunchKernelGGL(k_debug_triangle_tests<true>, grid, block, 0, 0, d_o.p, d_d.p, n_rays, d_t.p, n_tris, d_out.p);
+    else hipLaunchKernelGGL(k_debug_triangle_tests<false>, grid, block, 0, 0, d_o.p, d_d.p, n_rays, d_t.p, n_tris, d_out.p);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(RT_ERR_HIP, "kernel or copy failed"));
+    return done(RT_OK);
+}
+
 int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* material_ids, const float* materials, uint32_t n_mat) {
     if (!a || !material_ids || !materials) return fail(RT_ERR_INVALID, "null argument");
     if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");

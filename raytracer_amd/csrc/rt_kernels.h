@@ -381,6 +381,44 @@ __global__ void __launch_bounds__(256) k_stats_rays(DevOctree T, const float* __
     stats_flush<ANY>(c, totals);
 }
 
+// Diagnostics: every (ray, triangle) pair through the three forms of the ray/triangle test -- the compiled one
+// (ray_triangle<>), the hand-scheduled any-hit form with the triangle in scalar registers (any_hit_exec) and the one with
+// the triangle per lane (any_hit_exec_pairs) -- with an unbounded limit, so that each reports every usable hit.
+// out[form][ray * n_tris + tri] = the distance the form computed, +inf where it reports no hit.
+template <bool CULL>
+__global__ void __launch_bounds__(256) k_debug_triangle_tests(const float* __restrict__ orig, const float* __restrict__ dir, uint32_t n_rays,
+                                                              const LeafTri* __restrict__ tris, uint32_t n_tris, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n_rays;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (valid) {
+        o = mk(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
+        d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
+    }
+    const lanemask all = ballot64(valid);
+    const size_t plane = (size_t)n_rays * n_tris;
+    for (uint32_t j = 0; j < n_tris; ++j) {
+        cu32_p rec = as_const_u(tris) + (size_t)j * 12;  // wave-uniform: scalar loads
+        const float ax = __uint_as_float(rec[0]), ay = __uint_as_float(rec[1]), az = __uint_as_float(rec[2]);
+        const float e1x = __uint_as_float(rec[3]), e1y = __uint_as_float(rec[4]), e1z = __uint_as_float(rec[5]);
+        const float e2x = __uint_as_float(rec[6]), e2y = __uint_as_float(rec[7]), e2z = __uint_as_float(rec[8]);
+        float t0 = RT_INF;
+        const lanemask h0 = ray_triangle<CULL>(all, o, d, mk(ax, ay, az), mk(e1x, e1y, e1z), mk(e2x, e2y, e2z), t0);
+        lanemask h1 = 0;
+        float t1 = RT_INF;
+        any_hit_exec<CULL>(all, o, d, ax, ay, az, e1x, e1y, e1z, e2x, e2y, e2z, RT_INF, h1, 0, 0, &t1);
+        const LeafTri g = tris[j];  // per lane: vector registers
+        float t2 = RT_INF;
+        const lanemask h2 = any_hit_exec_pairs<CULL>(all, o, d, mk(g.ax, g.ay, g.az), mk(g.e1x, g.e1y, g.e1z), mk(g.e2x, g.e2y, g.e2z), RT_INF, &t2);
+        if (valid) {
+            const size_t at = (size_t)i * n_tris + j;
+            out[at] = lane_of(h0) ? t0 : RT_INF;
+            out[plane + at] = lane_of(h1) ? t1 : RT_INF;
+            out[2 * plane + at] = lane_of(h2) ? t2 : RT_INF;
+        }
+    }
+}
+
 // ---- renderer level kernels ------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void load_ray(const FrameParams& F, const RayRec* __restrict__ rays, uint32_t level, uint32_t i, uint32_t n,

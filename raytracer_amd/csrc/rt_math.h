@@ -70,13 +70,22 @@ __device__ __forceinline__ float div_refined(float n, float d, float r1) {
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ f3 reciprocal3(f3 d, bool need) {
-    const float lo = __builtin_fminf(__builtin_fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    const float hi = __builtin_fmaxf(__builtin_fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    // The range rcp_refined is checked on.  fminf / fmaxf drop a NaN operand, so a NaN component does not by itself
-    // force the true division; it does not need to: both forms return a NaN for that component, and no caller lets
-    // a reciprocal reach an output -- it only feeds comparisons, which a NaN fails whatever its sign and payload.
+    // The range rcp_refined is checked on: every component of every lane that matters is either inside it or an exact
+    // zero, whose reciprocal is written down directly (+-inf with the zero's sign, what 1.0f / d gives) -- the primary
+    // rays of an image wider than high all have dir.y == 0 (the reference's integer aspect ratio, renderer.cc:93), and a
+    // zero component must not send the other two down the full division.  fminf / fmaxf drop a NaN operand, so a NaN
+    // component does not by itself force the true division; it does not need to: both forms return a NaN for that
+    // component, and no caller lets a reciprocal reach an output -- it only feeds comparisons, which a NaN fails whatever
+    // its sign and payload.
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const float lo = __builtin_fminf(__builtin_fminf(ax == 0.0f ? 1.0f : ax, ay == 0.0f ? 1.0f : ay), az == 0.0f ? 1.0f : az);
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
     const bool in_range = lo >= kEps && hi <= kDivFastMax;
-    if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) return f3{rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z)};
+    if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) {
+        const float ix = rcp_refined(d.x), iy = rcp_refined(d.y), iz = rcp_refined(d.z);
+        return f3{ax == 0.0f ? __builtin_copysignf(RT_INF, d.x) : ix, ay == 0.0f ? __builtin_copysignf(RT_INF, d.y) : iy,
+                  az == 0.0f ? __builtin_copysignf(RT_INF, d.z) : iz};
+    }
     return f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 }
 #endif

@@ -207,10 +207,11 @@ __device__ __forceinline__ lanemask ray_triangle(lanemask mine, f3 o, f3 s, f3 a
 // MASKED = false: tests the lanes of `need`.  MASKED = true: `need` is the set of lanes that carry a ray; the lanes tested
 // are those of them that have no occluder yet and whose `reach` (the leaves the lane reaches) intersects lm (the leaves
 // that list the triangle) -- the selection of the small-tree and clustered passes, folded into the EXEC mask as well.
+// t_seen (diagnostics): receives, for the lanes added to `found`, the distance the last stage computed.
 template <bool CULL, bool MASKED = false>
 __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax, float ay, float az, float e1x, float e1y, float e1z,
                                              float e2x, float e2y, float e2z, float t_limit, lanemask& found, uint32_t reach = 0,
-                                             uint32_t lm = 0) {
+                                             uint32_t lm = 0, float* t_seen = nullptr) {
     float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
     lanemask save;
     const float eps = kEps;
@@ -218,19 +219,21 @@ __device__ __forceinline__ void any_hit_exec(lanemask need, f3 o, f3 s, float ax
     else if constexpr (MASKED) RT_ANY_HIT_ASM(RT_ANY_HIT_MASKED_PROLOGUE, RT_ANY_HIT_NOCULL, "s", RT_ANY_HIT_MASKED_INPUTS);
     else if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, "s", );
     else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, "s", );
+    if (t_seen) *t_seen = d;
 }
 
 // The same test for one (ray, triangle) pair per lane: every lane brings its own ray, triangle and limit in vector
 // registers (the pair phases of the per-lane and task-pool forms).  Returns the lanes of `need` whose pair is an
 // occluder.  Same caller's guarantee as above.
 template <bool CULL>
-__device__ __forceinline__ lanemask any_hit_exec_pairs(lanemask need, f3 o, f3 s, f3 a, f3 e1, f3 e2, float t_limit) {
+__device__ __forceinline__ lanemask any_hit_exec_pairs(lanemask need, f3 o, f3 s, f3 a, f3 e1, f3 e2, float t_limit, float* t_seen = nullptr) {
     float p0, p1, p2, d, r, e, q0, q1, q2, u, t0;
     lanemask save, found = 0;
     const float eps = kEps;
     const float ax = a.x, ay = a.y, az = a.z, e1x = e1.x, e1y = e1.y, e1z = e1.z, e2x = e2.x, e2y = e2.y, e2z = e2.z;
     if constexpr (CULL) RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_CULL, "v", );
     else RT_ANY_HIT_ASM("s_mov_b64 exec, %[need]\n", RT_ANY_HIT_NOCULL, "v", );
+    if (t_seen) *t_seen = d;
     return found;
 }
 

@@ -240,6 +240,67 @@ def test_clustered_any_hit_form(rt, orc, scenes, monkeypatch, scene, mb, md):
         assert np.abs(img - ref).max() <= 1.0 / 255.0 and st.rays == ost.search_calls
 
 
+def test_distances_of_the_three_triangle_test_forms(rt, orc):
+    """collision_ray_triangle (collision_detection.h:12-68) exists three times in the kernels: compiled (ray_triangle<>),
+    hand-scheduled with the triangle in scalar registers (any_hit_exec) and hand-scheduled with one triangle per lane
+    (any_hit_exec_pairs).  The two hand-scheduled forms restate the reciprocal's refinement chain in their own
+    instructions and normally only hand back a flag; rt_debug_triangle_tests makes all three return the DISTANCE they
+    computed for every (ray, triangle) pair: the same bits everywhere, both culling modes, and -- through a root-leaf
+    tree, whose Search returns every triangle -- the closest of them equal to the oracle's closest hit."""
+    import ctypes as C
+    from raytracer_amd import _capi
+    rng = np.random.default_rng(77)
+    n_tris = 12
+    tris = (rng.uniform(-3, 3, (n_tris, 1, 3)) + rng.normal(0, 1.2, (n_tris, 3, 3))).astype(np.float32)
+    tris[3] = tris[2][[0, 2, 1]]       # the same triangle with the opposite winding
+    tris[5, 0] = tris[4, 0]            # a shared vertex ...
+    tris[5, 1] = tris[4, 1]            # ... and a shared edge
+    origins, targets = [], []
+    for k in range(6000):
+        t = tris[rng.integers(n_tris)]
+        mode = k % 6
+        if mode == 0:    # a vertex, exactly
+            p = t[rng.integers(3)]
+        elif mode == 1:  # a point on an edge
+            a, b = t[rng.integers(3)], t[rng.integers(3)]
+            w = np.float32(rng.uniform())
+            p = a + (b - a) * w
+        elif mode == 2:  # grazing: a point in the triangle's plane just outside
+            u, v = rng.uniform(0.9, 1.1), rng.uniform(-0.1, 0.1)
+            p = t[0] + (t[1] - t[0]) * np.float32(u) + (t[2] - t[0]) * np.float32(v)
+        else:            # inside
+            u, v = rng.uniform(), rng.uniform()
+            if u + v > 1:
+                u, v = 1 - u, 1 - v
+            p = t[0] + (t[1] - t[0]) * np.float32(u) + (t[2] - t[0]) * np.float32(v)
+        o = rng.uniform(-8, 8, 3).astype(np.float32)
+        if mode == 5:    # an origin on the surface itself (secondary and shadow rays start there)
+            o, p = p.astype(np.float32), rng.uniform(-8, 8, 3).astype(np.float32)
+        origins.append(o)
+        targets.append(np.asarray(p, np.float32))
+    o = np.asarray(origins, np.float32)
+    d = np.asarray(targets, np.float32) - o
+    ln = np.sqrt((d * d).sum(1, dtype=np.float32), dtype=np.float32)
+    d = (d / np.maximum(ln, np.float32(1e-30))[:, None]).astype(np.float32)
+    d[::97] = 0.0  # zero-length directions (renderer.cc:187 skips such rays, the test must still agree)
+    n = o.shape[0]
+    sc = orc.Scene.from_arrays(tris, None, np.zeros(n_tris, np.int32), np.zeros((1, 18), np.float32))
+    ot = orc.Octree(sc, 16, 10)  # 12 triangles <= 16: the root is a leaf, every triangle is a candidate of every ray
+    for cull in (1, 0):
+        out = np.zeros((3, n, n_tris), np.float32)
+        _capi.check(_capi.lib().rt_debug_triangle_tests(0, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), n,
+                                                        np.ascontiguousarray(tris).ctypes.data_as(C.c_void_p), n_tris, cull,
+                                                        out.ctypes.data_as(C.c_void_p)))
+        u = out.view(np.uint32)
+        assert np.array_equal(u[0], u[1]), cull  # the scalar-register form computes the compiled form's distances
+        assert np.array_equal(u[0], u[2]), cull  # so does the per-lane form
+        hits = np.isfinite(out[0])
+        assert hits.sum() > 3000 and (~hits).sum() > 3000
+        ref_t, ref_tri = ot.trace_closest(o, d, cull=bool(cull))
+        best = out[0].min(axis=1)
+        assert np.array_equal(best.view(np.uint32), np.asarray(ref_t, np.float32).view(np.uint32)), cull
+
+
 def test_hand_scheduled_any_hit_test_and_its_range_gate(rt, orc, scenes, monkeypatch):
     """Shadow rays of scenes whose triangles are small enough use a triangle test whose reciprocal never takes the full
     division; it must give the oracle's flags in the small-tree pass too, and a scene beyond the bound (edges of 1e8
@@ -812,4 +873,4 @@ def test_dropin_behind_reference_ads_interface(scenes, tmp_path):
             f.write(pos.tobytes())
         p = subprocess.run([exe, str(raw), "1500"], capture_output=True, text=True, timeout=100)
         assert p.returncode == 0, p.stderr[-500:]
-        assert "DROPIN PASS" in p.stdout
+        assert "DROPIN PASS" in p.stdout and "segments=" in p.stdout  # Search lists, PrintStats text, closest hits, any-hit flags
