@@ -3,7 +3,8 @@
 # the program directly after `--`) of a short bench run, condensed by tools/summarize_pmc.py into
 # gpurun_out/profiles_new/<tag>_pmc_counters.json (+ the --stats table of the default workload).
 # usage (on the GPU box, from the repository root): tools/pmc_profile.sh <tag> [workload ...]
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
+export RT_BENCH_STREAMS=1  # counters and durations per kernel: no concurrent sub-frames
 WLS=${@:-cornell_original_blinn_spt16_1080p cornell_sphere_blinn_smooth_spp4_1080p synthetic_ico8_phong_4k}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
