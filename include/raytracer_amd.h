@@ -216,6 +216,10 @@ typedef struct rt_render_stats {
     /* The events cover at most the first 64 launches of each class per call; these are the rays of exactly the timed
      * launches, so that rays / ms is a kernel rate also for frames with more launches (many samples per pixel). */
     uint64_t timed_closest_rays, timed_shadow_rays;
+    /* Scenes whose materials spawn at most one secondary ray per hit: once a recursion level is small, the rest of the
+     * recursion (closest hits, shadow rays, shading of every deeper level) runs as ONE launch; its time and count. */
+    float ms_tail;
+    uint32_t launches_tail;
 } rt_render_stats;
 
 /* Renderer::RenderScene's hot loop (src/Renderer/renderer.cc:37-52) on the device: primary rays

@@ -132,13 +132,14 @@ struct FrameCtx {
     DevBuf<FrameTotals> d_totals;
     uint32_t slot_seq = 0;
     DevBuf<float> d_accum;
+    DevBuf<float> d_tail;  // k_tail: (colour, factor) per fused level and path
     hipEvent_t ev[2 + 6 * kMaxTimed] = {};
     bool events_ready = false;
     hipStream_t own_stream = nullptr;  // sub-frames 1..: a stream of the library's own
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void release() {
         for (auto& l : levels) l.release();
-        d_counters.release(); d_totals.release(); d_accum.release();
+        d_counters.release(); d_totals.release(); d_accum.release(); d_tail.release();
         if (h_slots) (void)hipHostFree(h_slots);
         if (h_totals) (void)hipHostFree(h_totals);
         if (events_ready)
@@ -212,6 +213,7 @@ class SubFramePool {
 };
 
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
+constexpr uint32_t kTailMaxRays = 1u << 18;
 constexpr bool kClipDefault = true;  // RT_CLIP=0: every ray walks the whole line like the reference (same results)
 constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots are walked by the wave together, whatever the rays
 
@@ -285,6 +287,7 @@ struct rt_ads {
     // walk only the part of a ray that can contribute a result (Span in rt_traverse.h); false: the reference's whole line
     bool clip = false;
     uint32_t pool_target_waves = 8192, lane_target_waves = 2048, pool_min_rays = 1;
+    uint32_t tail_max_rays = kTailMaxRays;  // levels with at most this many rays end the level-by-level loop (k_tail); 0 = never
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
     uint64_t n_tri = 0;
@@ -955,6 +958,8 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     a->pool_target_waves = 8192;
     a->pool_min_rays = 1;
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
+    a->tail_max_rays = kTailMaxRays;
+    if (const char* e = getenv("RT_TAIL_MAX_RAYS")) a->tail_max_rays = (uint32_t)atoi(e);
     a->lane_target_waves = 2048;
     if (const char* e = getenv("RT_LANE_WAVES")) a->lane_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
@@ -1541,7 +1546,8 @@ namespace {
 // One sub-frame of rt_render: the bands c->band_rank of c->band_world, rendered into the device frame buffer d_out with
 // the level buffers of `x`, on `stream`; returns after the stream has drained.  The instrumented pass (collect_stats) is
 // begun and ended by the caller.
-int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out, hipStream_t stream, rt_render_stats& st_out) {
+// n_sub: the sub-frames in flight on this GPU (this one included).
+int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out, hipStream_t stream, int n_sub, rt_render_stats& st_out) {
     if (int rc = use_device(a)) return rc;  // (a worker thread starts on device 0)
     FrameParams F;
     uint32_t n0 = 0;
@@ -1560,11 +1566,11 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
     // starts the next one's (an event costs the stream about 5 us; two per boundary were 2-3 % of a 2.5 ms frame).
     // mark(cls) closes the open interval and opens one of class cls; CLS_OTHER only closes.  At most kMaxTimed
     // intervals per class are taken per call.
-    enum { CLS_OTHER = 0, CLS_CLOSEST = 1, CLS_SHADOW = 2, CLS_SHADE = 3 };
+    enum { CLS_OTHER = 0, CLS_CLOSEST = 1, CLS_SHADOW = 2, CLS_SHADE = 3, CLS_TAIL = 4 };
     constexpr int kMaxMarks = 6 * kMaxTimed;
     hipEvent_t* ev_total = x.ev;
     hipEvent_t* ev_mark = x.ev + 2;
-    int n_marks = 0, n_cls[4] = {0, 0, 0, 0};
+    int n_marks = 0, n_cls[5] = {0, 0, 0, 0, 0};
     uint8_t mark_cls[kMaxMarks];
     bool last_timed = false;
     auto mark = [&](int cls) -> int {
@@ -1592,21 +1598,50 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
     x.slot_seq = seq_base + (uint32_t)c->samples_per_pixel + 1u;  // the next frame starts beyond every sequence number of this one
     hipLaunchKernelGGL(k_frame_begin, dim3(1), block, 0, stream, x.d_counters.p, max_levels, x.h_slots, seq_base, x.d_totals.p);
     HIP_TRY(hipGetLastError());
-    x.h_totals->secondary_rays = x.h_totals->shadow_rays = 0;
+    x.h_totals->secondary_rays = x.h_totals->shadow_rays = x.h_totals->deepest_level = 0;
     uint32_t level_seq[kMaxLevels];
     for (auto& q : level_seq) q = seq_base;
     const bool lit = (c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG) && a->n_lights > 0 && c->samples_per_triangle > 0;
     const uint32_t words = (uint32_t)((std::max(c->samples_per_triangle, 1) + 31) / 32);
     uint32_t level_n[kMaxLevels] = {};  // launch bound of each level of the current sample (resolve pass)
+    // the fused tail: chains only (no material reflects AND refracts), the per-lane form, all shadow rays of a hit within
+    // one wave; the instrumented pass counts level by level
+    uint32_t pshift_all = 0;
+    while ((1u << pshift_all) < (uint32_t)std::max(c->samples_per_triangle, 1) && pshift_all < 30) ++pshift_all;
+    const bool tail_ok = !a->collect_stats && !a->branching && a->tail_max_rays > 0 && traversal_mode(a, false, false, 1) == MODE_LANE &&
+                         (!lit || ((uint64_t)a->n_lights << pshift_all) <= 64);
     for (int s = 0; s < c->samples_per_pixel && n0 > 0; ++s) {
         F.spp_sample = (uint32_t)s;
         uint32_t cap = n0, levels = 0;  // cap: upper bound of the level's ray count (exact for level 0)
         for (uint32_t L = 0; L < max_levels && cap > 0; ++L) {
             Level& lv = x.levels[L];
+            uint32_t* cnt = x.d_counters.p + (size_t)L * CNT_WORDS;
+            // A small level of a scene whose paths are chains: the rest of the recursion runs as one launch (k_tail).
+            // (what decides is the load of the whole GPU: concurrent sub-frames share the limit)
+            if (L > 0 && tail_ok && (uint64_t)cap * (uint64_t)n_sub <= a->tail_max_rays) {
+                uint32_t pshift_t = 0, gshift_t = 0;
+                while ((1u << pshift_t) < (uint32_t)std::max(c->samples_per_triangle, 1)) ++pshift_t;
+                while (lit && (1u << gshift_t) < (a->n_lights << pshift_t)) ++gshift_t;
+                const uint32_t sparse_t = pool_sparse(a, MODE_LANE, (uint64_t)cap << gshift_t, 1u << gshift_t);
+                const dim3 grid_t((uint32_t)(mode_threads(MODE_LANE, (uint64_t)cap << gshift_t, sparse_t) / 64u));
+                HIP_TRY(x.d_tail.reserve((size_t)(max_levels - L) * cap * 6));
+                if (int rc = mark(CLS_TAIL)) return rc;
+                const size_t lds_t = lane_lds(a, MODE_LANE, 64, true);
+                const uint32_t opts_t = launch_opts(a, sparse_t);
+#define RT_TAIL(CULL, FAST) hipLaunchKernelGGL((k_tail<CULL, FAST>), grid_t, dim3(64), lds_t, stream, S, F, L, lv.rays.p, cap, x.levels[L - 1].out.p, \
+                                               x.d_tail.p, pshift_t, gshift_t, cnt, opts_t)
+                if (F.cull && a->fast_tri) RT_TAIL(true, true);
+                else if (F.cull) RT_TAIL(true, false);
+                else if (a->fast_tri) RT_TAIL(false, true);
+                else RT_TAIL(false, false);
+#undef RT_TAIL
+                HIP_TRY(hipGetLastError());
+                st.launches_tail++;
+                break;
+            }
             HIP_TRY(lv.reserve(cap, L > 0));
             lv.n = cap;
             level_n[L] = cap;
-            uint32_t* cnt = x.d_counters.p + (size_t)L * CNT_WORDS;
             const uint32_t* n_dev = L > 0 ? cnt - CNT_WORDS + CNT_NEXT : nullptr;
             const LevelSlot* slot = x.h_slots + L;
             const uint32_t seq = ++level_seq[L];  // CNT_SEQ of the level after this launch
@@ -1731,10 +1766,12 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
         HIP_TRY(hipEventElapsedTime(&ms, ev_mark[k], ev_mark[k + 1]));
         if (mark_cls[k] == CLS_CLOSEST) st.ms_closest += ms;
         else if (mark_cls[k] == CLS_SHADOW) st.ms_shadow += ms;
+        else if (mark_cls[k] == CLS_TAIL) st.ms_tail += ms;
         else st.ms_shade += ms;
     }
     st.secondary_rays = x.h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
     st.shadow_rays = x.h_totals->shadow_rays;
+    st.levels = std::max(st.levels, (uint32_t)x.h_totals->deepest_level);
     st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
     st_out = st;
     return RT_OK;
@@ -1782,7 +1819,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     int sub_rc[kMaxRenderStreams] = {};
     char sub_err[kMaxRenderStreams][sizeof g_err] = {};
     if (n_sub == 1) {
-        sub_rc[0] = render_bands(a, a->frame[0], c, d_out, stream, sub_stats[0]);
+        sub_rc[0] = render_bands(a, a->frame[0], c, d_out, stream, 1, sub_stats[0]);
         if (sub_rc[0]) return sub_rc[0];
     } else {
         if (!a->pool || a->pool->workers() < n_sub - 1) {
@@ -1802,7 +1839,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
             rt_render_config sub = *c;
             sub.band_world = c->band_world * n_sub;
             sub.band_rank = c->band_rank + k * c->band_world;
-            sub_rc[k] = render_bands(a, a->frame[k], &sub, d_out, k == 0 ? stream : a->frame[k].own_stream, sub_stats[k]);
+            sub_rc[k] = render_bands(a, a->frame[k], &sub, d_out, k == 0 ? stream : a->frame[k].own_stream, n_sub, sub_stats[k]);
             if (sub_rc[k]) snprintf(sub_err[k], sizeof sub_err[k], "%s", g_err);  // (the message is the worker thread's)
         };
         a->pool->run(n_sub, job);
@@ -1814,9 +1851,10 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         const rt_render_stats& s = sub_stats[k];
         st.primary_rays += s.primary_rays; st.secondary_rays += s.secondary_rays; st.shadow_rays += s.shadow_rays; st.rays += s.rays;
         st.levels = std::max(st.levels, s.levels);
-        st.ms_closest += s.ms_closest; st.ms_shadow += s.ms_shadow; st.ms_shade += s.ms_shade;
+        st.ms_closest += s.ms_closest; st.ms_shadow += s.ms_shadow; st.ms_shade += s.ms_shade; st.ms_tail += s.ms_tail;
         st.ms_total = std::max(st.ms_total, s.ms_total);
         st.launches_closest += s.launches_closest; st.launches_shadow += s.launches_shadow; st.launches_shade += s.launches_shade;
+        st.launches_tail += s.launches_tail;
         st.timed_closest_rays += s.timed_closest_rays; st.timed_shadow_rays += s.timed_shadow_rays;
     }
     if (mem == RT_MEM_HOST) {

@@ -175,8 +175,9 @@ struct FrameParams {
 // sample.  CNT_SEQ (launches of the level's closest-hit pass so far) and CNT_SLOT (address of the level's LevelSlot in
 // pinned host memory, 64 bits, 0 = nobody listens) are set up by k_frame_begin and live for the whole frame; keeping them
 // here rather than in kernel arguments keeps the traversal kernels' scalar register count where it was.
+// CNT_DEEPEST (k_tail): the deepest recursion level a path of the fused tail reached, + 1.
 enum { CNT_WORK = 0, CNT_NEXT = 32, CNT_SHADOW_LO = 64, CNT_SHADOW_HI = 65, CNT_SPAWN = 96, CNT_TICKET = 128, CNT_SEQ = 129,
-       CNT_SLOT_LO = 130, CNT_SLOT_HI = 131, CNT_WORDS = 160 };
+       CNT_SLOT_LO = 130, CNT_SLOT_HI = 131, CNT_DEEPEST = 132, CNT_WORDS = 160 };
 
 // What the host needs to know about a level to size the launches that follow, written by the last block of the
 // level's closest-hit pass straight into pinned host memory (flag last, system-scope release): the host polls the
@@ -193,7 +194,7 @@ static_assert(sizeof(LevelSlot) == 32, "");
 
 // Frame totals kept on the device between the samples of a frame (k_roll_counters) and mirrored into pinned host memory.
 struct FrameTotals {
-    unsigned long long secondary_rays, shadow_rays;
+    unsigned long long secondary_rays, shadow_rays, deepest_level;
 };
 
 // ---- helpers ---------------------------------------------------------------------------------------------------
@@ -653,30 +654,24 @@ __device__ __forceinline__ float shade_pow(float x, float y) {
     return (y == 0.0f || x == 1.0f) ? 1.0f : r;
 }
 
-// Local illumination + recursion gate + secondary ray construction for every hit of one level
-// (renderer.cc:144-192, 202-335); the visibility of each light sample comes from k_shadow.
-__global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
-                                               const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
-                                               const uint32_t* __restrict__ work, const uint32_t* __restrict__ vis, uint32_t words,
-                                               NodeOut* __restrict__ out, RayRec* __restrict__ next, uint32_t next_cap,
-                                               uint32_t* __restrict__ counters) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_work = counters[CNT_WORK];
-    const bool active = j < n_work;
-    uint32_t i = 0;
-    if (active) i = work[j];
-    bool valid;
-    f3 o, d;
-    uint32_t pixel, node_id;
-    load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
-    valid = valid && active;
-    float t = 0.0f;
-    uint32_t tri = 0;
-    if (valid) {
-        t = hit_t[i];
-        tri = (uint32_t)hit_tri[i];
-    }
-    const TriShade ts = S.tri_shade[tri];
+// What ray_color (renderer.cc:144-192) makes of one hit: the clamped local colour, the material's factors for the
+// children's colours, and the secondary rays the hit spawns.
+struct ShadeResult {
+    f3 col;                // clamped local colour (renderer.cc:170)
+    f3 fR, fT;             // material.specular / material.transmittance
+    f3 P;                  // the hit point (origin of the secondary rays)
+    f3 dir_R, dir_T;
+    bool want_R, want_T;
+};
+
+// Local illumination + recursion gate + secondary ray construction for one hit per lane (renderer.cc:144-192, 202-335).
+// valid: the lane holds a hit (ray o, d; distance t; triangle tri).  vis_word(l, w): the visibility bits of samples
+// 32 w .. 32 w + 31 of light l for this hit (bit = 1: not shadowed).  Every lane of the wave must call it (one wave-level
+// test decides whether the specular power is needed at all).
+template <class VisWord>
+__device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& F, uint32_t level, bool valid, f3 o, f3 d, float t, uint32_t tri,
+                                          uint32_t pixel, uint32_t node_id, VisWord vis_word, ShadeResult& r) {
+    const TriShade ts = S.tri_shade[valid ? tri : 0u];
     const MatDev m = S.mats[valid ? ts.mat : 0];
     const f3 P = o + (d * t);  // renderer.cc:146
     f3 N = mk(ts.nx, ts.ny, ts.nz);
@@ -711,7 +706,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
             f3 acc = mk(0, 0, 0);
             uint32_t bits = 0;
             for (int s = 0; s < F.spt; ++s) {
-                if ((s & 31) == 0) bits = vis[((size_t)l * words + (uint32_t)(s >> 5)) * n_work + j];
+                if ((s & 31) == 0) bits = vis_word(l, (uint32_t)(s >> 5));
                 if (!((bits >> (s & 31)) & 1u)) continue;  // shadowed
                 const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
                 // renderer.cc:220-240
@@ -764,34 +759,192 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
             want_T = !eq_eps(dir_T, mk(0, 0, 0));  // renderer.cc:187
         }
     }
+    r.col = col;
+    r.fR = specular;
+    r.fT = mk(m.transmittance[0], m.transmittance[1], m.transmittance[2]);
+    r.P = P;
+    r.dir_R = dir_R;
+    r.dir_T = dir_T;
+    r.want_R = want_R;
+    r.want_T = want_T;
+}
+
+// shade_hit for every hit of one level; the visibility of each light sample comes from k_shadow.
+__global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
+                                               const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
+                                               const uint32_t* __restrict__ work, const uint32_t* __restrict__ vis, uint32_t words,
+                                               NodeOut* __restrict__ out, RayRec* __restrict__ next, uint32_t next_cap,
+                                               uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_work = counters[CNT_WORK];
+    const bool active = j < n_work;
+    uint32_t i = 0;
+    if (active) i = work[j];
+    bool valid;
+    f3 o, d;
+    uint32_t pixel, node_id;
+    load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
+    valid = valid && active;
+    float t = 0.0f;
+    uint32_t tri = 0;
     if (valid) {
-        NodeOut r;
-        r.c[0] = col.x; r.c[1] = col.y; r.c[2] = col.z;
-        for (int k = 0; k < 3; ++k) {
-            r.fR[k] = m.specular[k];
-            r.fT[k] = m.transmittance[k];
-            r.IR[k] = r.IT[k] = 0.0f;
+        t = hit_t[i];
+        tri = (uint32_t)hit_tri[i];
+    }
+    ShadeResult r;
+    shade_hit(S, F, level, valid, o, d, t, tri, pixel, node_id,
+              [&](uint32_t l, uint32_t w) { return vis[((size_t)l * words + w) * n_work + j]; }, r);
+    if (valid) {
+        NodeOut q;
+        q.c[0] = r.col.x; q.c[1] = r.col.y; q.c[2] = r.col.z;
+        q.fR[0] = r.fR.x; q.fR[1] = r.fR.y; q.fR[2] = r.fR.z;
+        q.fT[0] = r.fT.x; q.fT[1] = r.fT.y; q.fT[2] = r.fT.z;
+        for (int k = 0; k < 3; ++k) q.IR[k] = q.IT[k] = 0.0f;
+        q.flags = (r.want_R ? 1u : 0u) | (r.want_T ? 2u : 0u);
+        out[i] = q;
+    }
+    const uint32_t sR = wave_append(&counters[CNT_NEXT], r.want_R);
+    const uint32_t sT = wave_append(&counters[CNT_NEXT], r.want_T);
+    if (r.want_R && sR < next_cap) {
+        RayRec q;
+        q.o[0] = r.P.x; q.o[1] = r.P.y; q.o[2] = r.P.z;
+        q.d[0] = r.dir_R.x; q.d[1] = r.dir_R.y; q.d[2] = r.dir_R.z;
+        q.parent = i; q.pixel = pixel; q.node_id = node_id * 2;
+        q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        next[sR] = q;
+    }
+    if (r.want_T && sT < next_cap) {
+        RayRec q;
+        q.o[0] = r.P.x; q.o[1] = r.P.y; q.o[2] = r.P.z;
+        q.d[0] = r.dir_T.x; q.d[1] = r.dir_T.y; q.d[2] = r.dir_T.z;
+        q.parent = i; q.pixel = pixel; q.node_id = node_id * 2 + 1;
+        q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        next[sT] = q;
+    }
+}
+
+// The rest of the recursion in ONE launch, for scenes whose materials spawn at most one secondary ray per hit (reflect
+// or refract, never both): from level `first` on every path is a chain, and a lane follows its chain to the end --
+// closest hit, the hit's shadow rays, shading, the next ray -- instead of the host launching three kernels per level.
+// Deep levels are small (tens of thousands of rays) and each of their launches lasts as long as one wave's chain of
+// dependent steps plus a launch boundary; here the boundaries are gone and nothing waits for the slowest wave of a level.
+// A path owns 2^gshift neighbouring lanes: the first carries the path (its rays, its closest hits, its shading), and after
+// a hit lane `sub` traces shadow ray q = sub = light << pshift | sample (all lights of a hit side by side; the host uses
+// this kernel only if they fit 64 lanes).  The walks are the per-lane form's (work stealing included), the arithmetic is
+// that of k_closest / k_shadow / k_shade, so a frame has the same bits whichever way its levels are run.
+// Values: ray_color returns c + I_child * factor (renderer.cc:181-182,188-189); a path stores (c, factor) per level in
+// `stack` ([level - first][path][6]) and folds them from the deepest level up, then hands the result to its parent node
+// of level first - 1 like k_resolve does.  counters: the block of level `first` (CNT_NEXT of the block before it = the
+// number of paths); the secondary and shadow rays of all fused levels are added to it.
+template <bool CULL, bool FAST>
+__global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t first, const RayRec* __restrict__ rays, uint32_t n_bound,
+                                             NodeOut* __restrict__ parent_level, float* __restrict__ stack, uint32_t pshift, uint32_t gshift,
+                                             uint32_t* __restrict__ counters, uint32_t opts) {
+    __shared__ TraverseLds<MODE_LANE> lds[1];
+    const uint32_t n = min(counters[CNT_NEXT - CNT_WORDS], n_bound);
+    const uint32_t group = 1u << gshift;
+    bool lane_ok;
+    const uint64_t slot = ray_index((uint64_t)xcd_block() * blockDim.x + threadIdx.x, opts_sparse(opts), lane_ok);
+    const uint32_t j = (uint32_t)(slot >> gshift), sub = (uint32_t)slot & (group - 1u);
+    const uint32_t lane = __lane_id(), lead = lane - sub;  // (a group never straddles waves: group <= 64 >> sparse)
+    const bool carrier = lane_ok && sub == 0u && j < n;
+    const lanemask group_mask = group >= 64u ? ~0ull : ((1ull << group) - 1ull);
+    const bool lit = F.render_type >= 2 && F.spt > 0 && S.n_lights > 0;
+    const uint32_t per_light = 1u << pshift;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    uint32_t pixel = 0, node_id = 1, parent = 0;
+    if (carrier) {
+        const RayRec r = rays[j];
+        o = mk(r.o[0], r.o[1], r.o[2]);
+        d = mk(r.d[0], r.d[1], r.d[2]);
+        pixel = r.pixel;
+        node_id = r.node_id;
+        parent = r.parent;
+    }
+    const uint32_t first_node_id = node_id;
+    bool live = carrier;
+    uint32_t depth_n = 0, n_next = 0;
+    unsigned long long n_shadow = 0;
+    for (uint32_t level = first;; ++level) {
+        // ---- closest hit (renderer.cc:116-142)
+        HitState h;
+        trace<false, CULL, MODE_LANE>(S.tree, lds[0], opts, live, o, d, 0.0f, h);
+        const bool hit = live && !(h.t == RT_INF);
+        const f3 P = o + (d * h.t);  // renderer.cc:146
+        const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
+        uint32_t lights_traced = 0;
+        if (hit && lit) {  // renderer.cc:212-214: the light loop ends at the light the hit triangle itself is
+            const int32_t light_eq = S.tri_shade[h.tri].light_eq;
+            lights_traced = (light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights;
         }
-        r.flags = (want_R ? 1u : 0u) | (want_T ? 2u : 0u);
-        out[i] = r;
+        // ---- the hit's shadow rays (renderer.cc:217-219, 288-313), one per lane of the group
+        lanemask vis_bits = 0;
+        if (lit && ballot64(lights_traced != 0u) != 0) {
+            const f3 gP = mk(__shfl(P.x, (int)lead, 64), __shfl(P.y, (int)lead, 64), __shfl(P.z, (int)lead, 64));
+            const uint32_t g_pre = __shfl(pre, (int)lead, 64), g_traced = __shfl(lights_traced, (int)lead, 64);
+            const uint32_t l = sub >> pshift, smp = sub & (per_light - 1u);
+            const bool on = lane_ok && l < g_traced && smp < (uint32_t)F.spt;
+            const LightDev& L = S.lights[on ? l : 0u];
+            const f3 p_l = light_sample(L, g_pre, l, smp);
+            const f3 to_l = p_l - gP;  // renderer.cc:289-290
+            const float dist = length(to_l);
+            const f3 d_l = normalize(to_l);
+            HitState hs;
+            trace<true, CULL, MODE_LANE, FAST>(S.tree, lds[0], opts, on, gP, d_l, dist, hs);
+            const lanemask unshadowed = ballot64(on) & ~hs.found;
+            vis_bits = (unshadowed >> lead) & group_mask;
+        }
+        // ---- shading, recursion gate, the next ray (renderer.cc:144-192)
+        ShadeResult r;
+        shade_hit(S, F, level, hit, o, d, h.t, h.tri, pixel, node_id,
+                  [&](uint32_t l, uint32_t w) {
+                      const uint32_t bits = (uint32_t)(vis_bits >> ((l << pshift) + 32u * w));
+                      return per_light >= 32u ? bits : (bits & ((1u << per_light) - 1u));
+                  },
+                  r);
+        if (live) {
+            const bool child = r.want_R || r.want_T;
+            const f3 c = hit ? r.col : F.bg;  // renderer.cc:140-142: a miss is the background colour
+            const f3 f = r.want_R ? r.fR : r.fT;
+            float* e = stack + ((size_t)depth_n * n_bound + j) * 6;
+            e[0] = c.x; e[1] = c.y; e[2] = c.z;
+            e[3] = child ? f.x : 0.0f; e[4] = child ? f.y : 0.0f; e[5] = child ? f.z : 0.0f;
+            ++depth_n;
+            n_shadow += (unsigned long long)lights_traced * (unsigned long long)(uint32_t)F.spt;
+            if (child) {
+                ++n_next;
+                o = r.P;
+                d = r.want_R ? r.dir_R : r.dir_T;
+                node_id = node_id * 2u + (r.want_R ? 0u : 1u);
+            }
+            live = child;
+        }
+        if (ballot64(live) == 0) break;
     }
-    const uint32_t sR = wave_append(&counters[CNT_NEXT], want_R);
-    const uint32_t sT = wave_append(&counters[CNT_NEXT], want_T);
-    if (want_R && sR < next_cap) {
-        RayRec r;
-        r.o[0] = P.x; r.o[1] = P.y; r.o[2] = P.z;
-        r.d[0] = dir_R.x; r.d[1] = dir_R.y; r.d[2] = dir_R.z;
-        r.parent = i; r.pixel = pixel; r.node_id = node_id * 2;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        next[sR] = r;
+    if (carrier) {
+        // from the deepest node up: value = c + child value * factor (node_value)
+        const float* e = stack + ((size_t)(depth_n - 1u) * n_bound + j) * 6;
+        f3 v = mk(e[0], e[1], e[2]);
+        for (uint32_t k = depth_n - 1u; k-- > 0u;) {
+            e = stack + ((size_t)k * n_bound + j) * 6;
+            v = mk(e[0], e[1], e[2]) + (v * mk(e[3], e[4], e[5]));
+        }
+        float* dst = (first_node_id & 1u) ? parent_level[parent].IT : parent_level[parent].IR;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
     }
-    if (want_T && sT < next_cap) {
-        RayRec r;
-        r.o[0] = P.x; r.o[1] = P.y; r.o[2] = P.z;
-        r.d[0] = dir_T.x; r.d[1] = dir_T.y; r.d[2] = dir_T.z;
-        r.parent = i; r.pixel = pixel; r.node_id = node_id * 2 + 1;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-        next[sT] = r;
+    // the rays of the fused levels, for the frame's totals
+    uint32_t deepest = carrier ? first + depth_n : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        n_next += __shfl_xor(n_next, s, 64);
+        n_shadow += __shfl_xor(n_shadow, s, 64);
+        const uint32_t other = __shfl_xor(deepest, s, 64);
+        deepest = deepest > other ? deepest : other;
+    }
+    if (lane == 0) {
+        if (n_next) atomicAdd(&counters[CNT_NEXT], n_next);
+        if (n_shadow) atomicAdd((unsigned long long*)&counters[CNT_SHADOW_LO], n_shadow);
+        if (deepest) atomicMax(&counters[CNT_DEEPEST], deepest);
     }
 }
 
@@ -837,18 +990,24 @@ __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const Nod
 __global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ counters, uint32_t levels, FrameTotals* __restrict__ totals,
                                                        FrameTotals* __restrict__ host_totals) {
     __shared__ unsigned long long s_next, s_shadow;
-    if (threadIdx.x == 0) s_next = s_shadow = 0ull;
+    __shared__ uint32_t s_deepest;
+    if (threadIdx.x == 0) {
+        s_next = s_shadow = 0ull;
+        s_deepest = 0u;
+    }
     __syncthreads();
     for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
         const uint32_t* c = counters + (size_t)L * CNT_WORDS;
         atomicAdd(&s_next, (unsigned long long)c[CNT_NEXT]);
         atomicAdd(&s_shadow, (unsigned long long)c[CNT_SHADOW_LO] | ((unsigned long long)c[CNT_SHADOW_HI] << 32));
+        atomicMax(&s_deepest, c[CNT_DEEPEST]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         FrameTotals t = *totals;
         t.secondary_rays += s_next;
         t.shadow_rays += s_shadow;
+        t.deepest_level = t.deepest_level > s_deepest ? t.deepest_level : (unsigned long long)s_deepest;
         *totals = t;
         *host_totals = t;
         __threadfence_system();
@@ -856,7 +1015,7 @@ __global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ co
     __syncthreads();
     for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
         uint32_t* c = counters + (size_t)L * CNT_WORDS;
-        c[CNT_WORK] = c[CNT_NEXT] = c[CNT_SHADOW_LO] = c[CNT_SHADOW_HI] = c[CNT_SPAWN] = c[CNT_TICKET] = 0u;
+        c[CNT_WORK] = c[CNT_NEXT] = c[CNT_SHADOW_LO] = c[CNT_SHADOW_HI] = c[CNT_SPAWN] = c[CNT_TICKET] = c[CNT_DEEPEST] = 0u;
     }
 }
 
@@ -873,7 +1032,7 @@ __global__ void __launch_bounds__(256) k_frame_begin(uint32_t* __restrict__ coun
         c[CNT_SLOT_LO] = (uint32_t)p;
         c[CNT_SLOT_HI] = (uint32_t)((uint64_t)p >> 32);
     }
-    if (threadIdx.x == 0 && totals) totals->secondary_rays = totals->shadow_rays = 0ull;
+    if (threadIdx.x == 0 && totals) totals->secondary_rays = totals->shadow_rays = totals->deepest_level = 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_primary_hits(FrameParams F, const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
