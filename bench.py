@@ -52,7 +52,7 @@ WORKLOADS = {
     # 1,310,754 triangles (Cornell box + icosphere level 8), hard shadows, true aspect ratio
     "synthetic_ico8_phong_4k": dict(
         scene="synthetic:8", cam=CAM_ORIGINAL, width=3840, height=2160, spp=1, spt=1, render_type="phong",
-        shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160), streams=4),
+        shading="flat", cull=True, max_depth=10, aspect="true", cpu_rows=(1000, 1160), streams=3),
     # fuzzysampling (64 samples per pixel) + 32 samples per light, 4K
     "cornell_original_blinn_spp64_spt32_4k": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong",

@@ -287,6 +287,7 @@ struct rt_ads {
     // walk only the part of a ray that can contribute a result (Span in rt_traverse.h); false: the reference's whole line
     bool clip = false;
     uint32_t pool_target_waves = 8192, lane_target_waves = 2048, pool_min_rays = 1;
+    uint32_t tail_target_waves = 1024;
     uint32_t tail_max_rays = kTailMaxRays;  // levels with at most this many rays end the level-by-level loop (k_tail); 0 = never
     int builder = 0;    // rt_builder requested at creation
     bool device_built = false;
@@ -960,6 +961,8 @@ int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (const char* e = getenv("RT_POOL_WAVES")) a->pool_target_waves = (uint32_t)atoi(e);
     a->tail_max_rays = kTailMaxRays;
     if (const char* e = getenv("RT_TAIL_MAX_RAYS")) a->tail_max_rays = (uint32_t)atoi(e);
+    a->tail_target_waves = 1024;
+    if (const char* e = getenv("RT_TAIL_WAVES")) a->tail_target_waves = (uint32_t)atoi(e);
     a->lane_target_waves = 2048;
     if (const char* e = getenv("RT_LANE_WAVES")) a->lane_target_waves = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_POOL_MIN_RAYS")) a->pool_min_rays = (uint32_t)atoi(e);
@@ -1622,7 +1625,8 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 uint32_t pshift_t = 0, gshift_t = 0;
                 while ((1u << pshift_t) < (uint32_t)std::max(c->samples_per_triangle, 1)) ++pshift_t;
                 while (lit && (1u << gshift_t) < (a->n_lights << pshift_t)) ++gshift_t;
-                const uint32_t sparse_t = pool_sparse(a, MODE_LANE, (uint64_t)cap << gshift_t, 1u << gshift_t);
+                uint32_t sparse_t = 0;  // (fewer paths per wave while the launch stays below tail_target_waves waves)
+                while ((64u >> (sparse_t + 1)) >= (1u << gshift_t) && ((((uint64_t)cap << gshift_t) >> (6 - sparse_t)) < a->tail_target_waves)) ++sparse_t;
                 const dim3 grid_t((uint32_t)(mode_threads(MODE_LANE, (uint64_t)cap << gshift_t, sparse_t) / 64u));
                 HIP_TRY(x.d_tail.reserve((size_t)(max_levels - L) * cap * 6));
                 if (int rc = mark(CLS_TAIL)) return rc;
