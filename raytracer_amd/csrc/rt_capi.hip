@@ -86,6 +86,7 @@ struct DevBuf {  // grow-only device buffer
 struct Level {
     DevBuf<RayRec> rays;
     DevBuf<NodeOut> out;
+    DevBuf<float> child;  // kNodeChildFloats per node: the colours its children return
     DevBuf<float> hit_t;
     DevBuf<int32_t> hit_tri;
     DevBuf<uint32_t> work;
@@ -95,12 +96,13 @@ struct Level {
         hipError_t e;
         if (need_rays && (e = rays.reserve(count)) != hipSuccess) return e;
         if ((e = out.reserve(count)) != hipSuccess) return e;
+        if ((e = child.reserve((size_t)count * kNodeChildFloats)) != hipSuccess) return e;
         if ((e = hit_t.reserve(count)) != hipSuccess) return e;
         if ((e = hit_tri.reserve(count)) != hipSuccess) return e;
         return work.reserve(count);
     }
     void release() {
-        rays.release(); out.release(); hit_t.release(); hit_tri.release(); work.release(); vis.release();
+        rays.release(); out.release(); child.release(); hit_t.release(); hit_tri.release(); work.release(); vis.release();
     }
 };
 
@@ -1632,7 +1634,7 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 if (int rc = mark(CLS_TAIL)) return rc;
                 const size_t lds_t = lane_lds(a, MODE_LANE, 64, true);
                 const uint32_t opts_t = launch_opts(a, sparse_t);
-#define RT_TAIL(CULL, FAST) hipLaunchKernelGGL((k_tail<CULL, FAST>), grid_t, dim3(64), lds_t, stream, S, F, L, lv.rays.p, cap, x.levels[L - 1].out.p, \
+#define RT_TAIL(CULL, FAST) hipLaunchKernelGGL((k_tail<CULL, FAST>), grid_t, dim3(64), lds_t, stream, S, F, L, lv.rays.p, cap, x.levels[L - 1].child.p, \
                                                x.d_tail.p, pshift_t, gshift_t, cnt, opts_t)
                 if (F.cull && a->fast_tri) RT_TAIL(true, true);
                 else if (F.cull) RT_TAIL(true, false);
@@ -1745,10 +1747,12 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
         for (uint32_t L = levels; L-- > 1;) {
             Level& lv = x.levels[L];
             const uint32_t* n_dev = x.d_counters.p + (size_t)(L - 1) * CNT_WORDS + CNT_NEXT;
-            hipLaunchKernelGGL(k_resolve, dim3((level_n[L] + 255) / 256), block, 0, stream, lv.out.p, lv.rays.p, n_dev, x.levels[L - 1].out.p);
+            hipLaunchKernelGGL(k_resolve, dim3((level_n[L] + 255) / 256), block, 0, stream, lv.out.p, lv.child.p, lv.rays.p, n_dev, S.mats,
+                               x.levels[L - 1].child.p);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, x.levels[0].out.p, n0, x.d_accum.p, d_out);
+        hipLaunchKernelGGL(k_resolve_pixels, dim3((n0 + 255) / 256), block, 0, stream, F, x.levels[0].out.p, x.levels[0].child.p, S.mats, n0, x.d_accum.p,
+                           d_out);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_roll_counters, dim3(1), block, 0, stream, x.d_counters.p, max_levels, x.d_totals.p, x.h_totals);
         HIP_TRY(hipGetLastError());

@@ -139,13 +139,15 @@ struct alignas(16) RayRec {  // one node of the recursion tree waiting to be tra
 };
 static_assert(sizeof(RayRec) == 48, "");
 
-struct alignas(16) NodeOut {  // what ray_color (renderer.cc:114-195) knows about one node
+struct alignas(16) NodeOut {  // what ray_color (renderer.cc:114-195) knows about one node before its children return
     float c[3];               // clamped local colour (renderer.cc:170), or the background on a miss
-    float fR[3], fT[3];       // material.specular / material.transmittance
-    float IR[3], IT[3];       // colours returned by the children, filled in by k_resolve
-    uint32_t flags;           // bit0: has reflection child, bit1: has refraction child
+    uint32_t meta;            // bit 0: has a reflection child, bit 1: a refraction child; bits 2..: material of the hit
 };
-static_assert(sizeof(NodeOut) == 64, "");
+static_assert(sizeof(NodeOut) == 16, "");
+// The colours the children return (I_R, I_T of renderer.cc:180-189) live beside the nodes, 6 floats per node, and are
+// only touched for nodes that have children -- a level-0 node is written once per hit and read once per pixel, and
+// 16 bytes instead of 64 is what those two passes move.
+constexpr uint32_t kNodeChildFloats = 6;
 
 struct SceneDev {
     DevOctree tree;
@@ -472,8 +474,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) RT_CLOSEST_OCCUPANCY(MODE) k
         if (!hit) {  // renderer.cc:140-142: the background colour is this node's value
             NodeOut r;
             r.c[0] = F.bg.x; r.c[1] = F.bg.y; r.c[2] = F.bg.z;
-            for (int k = 0; k < 3; ++k) r.fR[k] = r.fT[k] = r.IR[k] = r.IT[k] = 0.0f;
-            r.flags = 0;
+            r.meta = 0;
             out[i] = r;
         }
     }
@@ -659,6 +660,7 @@ __device__ __forceinline__ float shade_pow(float x, float y) {
 struct ShadeResult {
     f3 col;                // clamped local colour (renderer.cc:170)
     f3 fR, fT;             // material.specular / material.transmittance
+    uint32_t mat;          // the hit triangle's material
     f3 P;                  // the hit point (origin of the secondary rays)
     f3 dir_R, dir_T;
     bool want_R, want_T;
@@ -762,6 +764,7 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
     r.col = col;
     r.fR = specular;
     r.fT = mk(m.transmittance[0], m.transmittance[1], m.transmittance[2]);
+    r.mat = valid ? (uint32_t)ts.mat : 0u;
     r.P = P;
     r.dir_R = dir_R;
     r.dir_T = dir_T;
@@ -797,10 +800,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
     if (valid) {
         NodeOut q;
         q.c[0] = r.col.x; q.c[1] = r.col.y; q.c[2] = r.col.z;
-        q.fR[0] = r.fR.x; q.fR[1] = r.fR.y; q.fR[2] = r.fR.z;
-        q.fT[0] = r.fT.x; q.fT[1] = r.fT.y; q.fT[2] = r.fT.z;
-        for (int k = 0; k < 3; ++k) q.IR[k] = q.IT[k] = 0.0f;
-        q.flags = (r.want_R ? 1u : 0u) | (r.want_T ? 2u : 0u);
+        q.meta = (r.want_R ? 1u : 0u) | (r.want_T ? 2u : 0u) | (r.mat << 2);
         out[i] = q;
     }
     const uint32_t sR = wave_append(&counters[CNT_NEXT], r.want_R);
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev S, FrameParams F, uint32
 // (118 vector registers, 4 waves per SIMD; forcing 5 to 7 waves with spills measured the same)
 template <bool CULL, bool FAST>
 __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t first, const RayRec* __restrict__ rays, uint32_t n_bound,
-                                             NodeOut* __restrict__ parent_level, float* __restrict__ stack, uint32_t pshift, uint32_t gshift,
+                                             float* __restrict__ parent_child, float* __restrict__ stack, uint32_t pshift, uint32_t gshift,
                                              uint32_t* __restrict__ counters, uint32_t opts) {
     __shared__ TraverseLds<MODE_LANE> lds[1];
     const uint32_t n = min(counters[CNT_NEXT - CNT_WORDS], n_bound);
@@ -930,7 +930,7 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
             e = stack + ((size_t)k * n_bound + j) * 6;
             v = mk(e[0], e[1], e[2]) + (v * mk(e[3], e[4], e[5]));
         }
-        float* dst = (first_node_id & 1u) ? parent_level[parent].IT : parent_level[parent].IR;
+        float* dst = parent_child + (size_t)parent * kNodeChildFloats + ((first_node_id & 1u) ? 3 : 0);
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
     }
     // the rays of the fused levels, for the frame's totals
@@ -951,32 +951,35 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
 
 // renderer.cc:181-182,188-189: final += I_R * specular; final += I_T * transmittance -- evaluated bottom-up,
 // one level per launch, each node handing its value to its parent.
-__device__ __forceinline__ f3 node_value(const NodeOut& r) {
+__device__ __forceinline__ f3 node_value(const NodeOut& r, const float* __restrict__ child, const MatDev* __restrict__ mats) {
     f3 v = mk(r.c[0], r.c[1], r.c[2]);
-    if (r.flags & 1u) v = v + (mk(r.IR[0], r.IR[1], r.IR[2]) * mk(r.fR[0], r.fR[1], r.fR[2]));
-    if (r.flags & 2u) v = v + (mk(r.IT[0], r.IT[1], r.IT[2]) * mk(r.fT[0], r.fT[1], r.fT[2]));
+    if (r.meta & 3u) {
+        const MatDev& m = mats[r.meta >> 2];
+        if (r.meta & 1u) v = v + (mk(child[0], child[1], child[2]) * mk(m.specular[0], m.specular[1], m.specular[2]));
+        if (r.meta & 2u) v = v + (mk(child[3], child[4], child[5]) * mk(m.transmittance[0], m.transmittance[1], m.transmittance[2]));
+    }
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_resolve(const NodeOut* __restrict__ cur, const RayRec* __restrict__ rays, const uint32_t* __restrict__ n_dev,
-                                                 NodeOut* __restrict__ parent_level) {
+__global__ void __launch_bounds__(256) k_resolve(const NodeOut* __restrict__ cur, const float* __restrict__ cur_child, const RayRec* __restrict__ rays,
+                                                 const uint32_t* __restrict__ n_dev, const MatDev* __restrict__ mats, float* __restrict__ parent_child) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *n_dev) return;
-    const f3 v = node_value(cur[i]);
+    const f3 v = node_value(cur[i], cur_child + (size_t)i * kNodeChildFloats, mats);
     const RayRec r = rays[i];
-    float* dst = (r.node_id & 1u) ? parent_level[r.parent].IT : parent_level[r.parent].IR;
+    float* dst = parent_child + (size_t)r.parent * kNodeChildFloats + ((r.node_id & 1u) ? 3 : 0);
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
 }
 
 // renderer.cc:42-51: sum over the samples of a pixel, divide, clamp.
-__global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const NodeOut* __restrict__ level0, uint32_t n,
-                                                        float* __restrict__ accum, float* __restrict__ out_rgb) {
+__global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const NodeOut* __restrict__ level0, const float* __restrict__ level0_child,
+                                                        const MatDev* __restrict__ mats, uint32_t n, float* __restrict__ accum, float* __restrict__ out_rgb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int x, y;
     if (!node0_pixel(F, i, x, y)) return;
     const size_t pix = (size_t)y * F.width + x;
-    f3 v = node_value(level0[i]);
+    f3 v = node_value(level0[i], level0_child + (size_t)i * kNodeChildFloats, mats);
     if (F.spp_sample > 0) v = mk(accum[i * 3], accum[i * 3 + 1], accum[i * 3 + 2]) + v;
     if ((int)F.spp_sample + 1 < F.spp) {
         accum[i * 3] = v.x; accum[i * 3 + 1] = v.y; accum[i * 3 + 2] = v.z;
