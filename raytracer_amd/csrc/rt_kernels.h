@@ -715,7 +715,7 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
                 const f3 to_l = p_l - P;
                 const float dist = length(to_l);
                 const f3 d_l = normalize(to_l);
-                const float w = (L.area * std_max(0.0f, dot(n_l, -d_l))) / ((float)F.spt * dist * dist + kEps);
+                const float w = div_scalar(L.area * std_max(0.0f, dot(n_l, -d_l)), (float)F.spt * dist * dist + kEps, true);
                 const f3 I_l = emission * w;
                 const f3 I_a = I_l * mk(0, 0, 0);
                 const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));

@@ -69,6 +69,16 @@ __device__ __forceinline__ float div_refined(float n, float d, float r1) {
 #endif
 
 #if defined(__HIPCC__)
+// n / d for the lanes with `need`: the refinement chain when every such lane has both operands inside the range it is
+// checked on (a zero numerator as well: the chain then carries zeros of the numerator's sign through every step, which is
+// the quotient), the true division otherwise.
+__device__ __forceinline__ float div_scalar(float n, float d, bool need) {
+    const float an = fabsf(n), ad = fabsf(d);
+    const bool in_range = (an == 0.0f || (an >= kDivFastMin && an <= kDivFastMax)) && ad >= kDivFastMin && ad <= kDivFastMax;
+    if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) return div_refined(n, d, div_refined_r1(d));
+    return n / d;
+}
+
 __device__ __forceinline__ f3 reciprocal3(f3 d, bool need) {
     // The range rcp_refined is checked on: every component of every lane that matters is either inside it or an exact
     // zero, whose reciprocal is written down directly (+-inf with the zero's sign, what 1.0f / d gives) -- the primary
