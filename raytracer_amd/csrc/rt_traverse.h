@@ -605,6 +605,117 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
     if (FLAT) flat_tests<ANY, CULL, FAST>(T, all, reach, o, d, t_limit, h);
 }
 
+// ---- ordered, pruned closest-hit walk of the wave ---------------------------------------------------------------------
+// The wave-together closest-hit walk with the upper end of the walked part following each lane's best hit (Span).  Two
+// things make the pruning bite.  Order: the octants of a node are pushed far to near in the octant order of the wave's
+// first ray (k -> octant k ^ flip, see node_ordered_nonempty), so the nearest is popped first -- any order gives the same
+// result, a good one finds the hits before the boxes behind them are opened.  And every stack entry carries the smallest
+// entry distance of the lanes it was pushed for: when it is popped, lanes whose best hit is nearer than that are dropped
+// without a load, and an entry no lane still wants costs two scalar instructions instead of a node visit or a leaf's
+// triangle tests.
+struct WaveStackT : WaveStack {
+    int ta = 0, tb = 0;  // per entry: bits of the smallest entry distance
+    __device__ __forceinline__ void push_t(uint32_t info0, uint32_t info1, lanemask m, float t_enter) {
+        const int lane = (int)__lane_id();
+        ta = (lane == sp) ? (int)__float_as_uint(t_enter) : ta;
+        tb = (lane + 64 == sp) ? (int)__float_as_uint(t_enter) : tb;
+        push(info0, info1, m);
+    }
+    __device__ __forceinline__ void pop_t(uint32_t& info0, uint32_t& info1, lanemask& m, float& t_enter) {
+        pop(info0, info1, m);  // (sp now indexes the popped entry)
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(ta, sp & 63), b = (uint32_t)__builtin_amdgcn_readlane(tb, sp & 63);
+        t_enter = __uint_as_float(sp < 64 ? a : b);
+    }
+};
+
+// Minimum over the wave of x (lanes that do not take part pass +inf), as a wave-uniform value.
+__device__ __forceinline__ float wave_min_f32(float x) {
+#define RT_MIN_STEP(CTRL, ROW_MASK)                                                                                         \
+    x = __builtin_fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false)))
+    RT_MIN_STEP(0x111, 0xf);  // row_shr:1 (lanes without a source keep their own value)
+    RT_MIN_STEP(0x112, 0xf);  // row_shr:2
+    RT_MIN_STEP(0x114, 0xf);  // row_shr:4
+    RT_MIN_STEP(0x118, 0xf);  // row_shr:8
+    RT_MIN_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    RT_MIN_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef RT_MIN_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// collision_detection.h:72-85 for octant c with the running bounds started at [lo, hi]; t_enter = the running maximum.
+__device__ __forceinline__ bool octant_interval(const SlabSides& s, const int c, float lo, float hi, float& t_enter) {
+    const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+    float t_min = slab_max(lo, s.tn[0][bx]), t_max = slab_min(hi, s.tf[0][bx]);
+    t_min = slab_max(t_min, s.tn[1][by]);
+    t_max = slab_min(t_max, s.tf[1][by]);
+    t_min = slab_max(t_min, s.tn[2][bz]);
+    t_max = slab_min(t_max, s.tf[2][bz]);
+    t_enter = t_min;
+    return t_max >= t_min;
+}
+
+template <int FLIP>
+__device__ __forceinline__ void push_octants_ordered(const SlabSides& sl, const u32x16& info, lanemask mine, float lo, float hi, WaveStackT& st) {
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {  // far to near
+        const int c = k ^ FLIP;
+        const uint32_t c1 = info[2 * c + 1];
+        if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
+        float t_enter;
+        const bool pass = octant_interval(sl, c, lo, hi, t_enter);
+        const lanemask pm = mine & ballot64(pass);
+        if (pm == 0) continue;
+        st.push_t(info[2 * c], c1, pm, wave_min_f32(lane_of(pm) ? t_enter : RT_INF));
+    }
+}
+
+template <bool CULL>
+__device__ __forceinline__ void traverse_packet_pruned(const DevOctree& T, lanemask all, f3 o, f3 d, float lo, HitState& h) {
+    const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
+    const float pad_abs = span_pad_abs(o);
+    // the octant order of the wave: that of its first ray
+    const uint32_t flip_lane = (inv.x < 0.0f ? 4u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 1u : 0u);
+    const uint32_t flip = (uint32_t)__builtin_amdgcn_readlane((int)flip_lane, __builtin_ctzll(all));
+    WaveStackT st;
+    cu32_p nodes = as_const_u(T.nodes);
+    uint32_t i0 = T.root_info0, i1 = T.root_info1;
+    lanemask mine = all;
+    for (;;) {
+        if (i1 & kChildInternal) {
+            cu32_p rec = nodes + (size_t)i0 * 32;
+            const u32x16 pl = sload16(rec);
+            const u32x16 info = sload16(rec + 16);
+            SlabSides sl;
+            slab_sides(pl, o, inv, sl);
+            const float hi = span_hi_closest(h.t, pad_abs);
+            switch (flip) {
+                case 0: push_octants_ordered<0>(sl, info, mine, lo, hi, st); break;
+                case 1: push_octants_ordered<1>(sl, info, mine, lo, hi, st); break;
+                case 2: push_octants_ordered<2>(sl, info, mine, lo, hi, st); break;
+                case 3: push_octants_ordered<3>(sl, info, mine, lo, hi, st); break;
+                case 4: push_octants_ordered<4>(sl, info, mine, lo, hi, st); break;
+                case 5: push_octants_ordered<5>(sl, info, mine, lo, hi, st); break;
+                case 6: push_octants_ordered<6>(sl, info, mine, lo, hi, st); break;
+                default: push_octants_ordered<7>(sl, info, mine, lo, hi, st); break;
+            }
+        } else {
+            leaf_tests<false, CULL, false>(T, i0, i1, mine, o, d, 0.0f, h);
+        }
+        // next entry that some lane can still gain from: a lane whose best hit is nearer than the entry's nearest point is out
+        bool got = false;
+        while (st.sp > 0) {
+            float t_enter;
+            st.pop_t(i0, i1, mine, t_enter);
+            mine &= ballot64(span_hi_closest(h.t, pad_abs) >= t_enter);
+            if (mine != 0) {
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+    }
+}
+
 // One record of a cluster's triangle list (record jj of the 4-record block).  lm = the cluster's leaves that list the
 // triangle, wreach = the leaves some lane of the wave reaches, reach = the leaves this lane reaches.
 template <bool CULL, bool FAST = false>
@@ -751,7 +862,8 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     for (;;) {
         HitState w;
         hit_state_reset(w);
-        traverse_impl<ANY, CULL, false, FAST>(T, todo, o, d, t_limit, Span{span_lo_closest(o, pruned), RT_INF}, pruned, w);
+        if (pruned) traverse_packet_pruned<CULL>(T, todo, o, d, span_lo_closest(o, true), w);
+        else traverse_impl<ANY, CULL, false, FAST>(T, todo, o, d, t_limit, span_all(), false, w);
         const bool mine = lane_of(todo);
         h.t = mine ? w.t : h.t;
         h.slot = mine ? w.slot : h.slot;
