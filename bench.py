@@ -132,12 +132,15 @@ def kernel_summary(acc, steps, work):
     """Per-kernel-class rates from the HIP-event times that rt_render reports (first 64 launches of each class per frame)."""
     shadow_rate = acc["shadow_rays"] / max(acc["shadow_ms"] * 1e-3, 1e-12)
     closest_rate = acc["closest_rays"] / max(acc["closest_ms"] * 1e-3, 1e-12)
-    out = {"k_shadow": {"launches": acc["shadow_launches"], "avg_launch_ms": acc["shadow_ms"] / max(acc["shadow_launches"], 1),
-                        "ms_per_frame": acc["shadow_ms"] / steps, "Mrays_per_s": shadow_rate / 1e6},
-           "k_closest": {"launches": acc["closest_launches"], "avg_launch_ms": acc["closest_ms"] / max(acc["closest_launches"], 1),
-                         "ms_per_frame": acc["closest_ms"] / steps, "Mrays_per_s": closest_rate / 1e6},
-           "k_shade": {"launches": acc["shade_launches"], "avg_launch_ms": acc["shade_ms"] / max(acc["shade_launches"], 1),
-                       "ms_per_frame": acc["shade_ms"] / steps}}
+    out = {}
+    for name, key in (("k_shadow", "shadow"), ("k_closest", "closest"), ("k_shade", "shade")):
+        timed, every = acc[key + "_launches"], acc[key + "_launches_all"]
+        avg = acc[key + "_ms"] / max(timed, 1)
+        out[name] = {"launches": timed, "avg_launch_ms": avg, "ms_per_frame": avg * every / steps}
+        if every != timed:  # frames with more than 64 launches of the class: the untimed ones are taken at the timed average
+            out[name]["launches_untimed"] = every - timed
+    out["k_shadow"]["Mrays_per_s"] = shadow_rate / 1e6
+    out["k_closest"]["Mrays_per_s"] = closest_rate / 1e6
     if work is not None:
         for name, rate, key in (("k_shadow", shadow_rate, "any_hit"), ("k_closest", closest_rate, "closest_hit")):
             tf = rate * work[key]["flops"] / 1e12
@@ -149,7 +152,7 @@ def kernel_summary(acc, steps, work):
 
 def new_acc():
     return dict(rays=0, shade_ms=0.0, closest_ms=0.0, shadow_ms=0.0, shade_launches=0, closest_launches=0, shadow_launches=0,
-                shadow_rays=0, closest_rays=0)
+                shade_launches_all=0, closest_launches_all=0, shadow_launches_all=0, shadow_rays=0, closest_rays=0)
 
 
 def add_stats(acc, st):
@@ -162,6 +165,9 @@ def add_stats(acc, st):
     acc["shade_launches"] += min(st.launches_shade, 64)
     acc["shadow_launches"] += min(st.launches_shadow, 64)
     acc["closest_launches"] += min(st.launches_closest, 64)
+    acc["shade_launches_all"] += st.launches_shade
+    acc["shadow_launches_all"] += st.launches_shadow
+    acc["closest_launches_all"] += st.launches_closest
     acc["shadow_rays"] += st.timed_shadow_rays
     acc["closest_rays"] += st.timed_closest_rays
 
