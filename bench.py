@@ -128,6 +128,24 @@ def reference_work(ads, rt, wl, max_rays=6e7):
             "counted_on": f"device, instrumented pass, {kw['width']}x{kw['height']} frame of the same workload, {q['counted_rays']} rays"}
 
 
+def committed_reference_work(workload):
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_bench_n1.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.loads(f.read().strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError):
+            continue
+        w = d.get("reference_work_per_ray") if d.get("config", {}).get("workload") == workload else \
+            d.get("other_workloads", {}).get(workload, {}).get("reference_work_per_ray")
+        if w and "counted_on" in w and not w["counted_on"].startswith("quoted"):
+            w = {k: v for k, v in w.items() if k != "cpu_cross_check"}
+            w["counted_on"] = f"quoted from profiles/{os.path.basename(path)}: " + w["counted_on"]
+            return w
+    return None
+
+
 def kernel_summary(acc, steps, work):
     """Per-kernel-class rates from the HIP-event times that rt_render reports (first 64 launches of each class per frame)."""
     shadow_rate = acc["shadow_rays"] / max(acc["shadow_ms"] * 1e-3, 1e-12)
@@ -139,6 +157,11 @@ def kernel_summary(acc, steps, work):
         out[name] = {"launches": timed, "avg_launch_ms": avg, "ms_per_frame": avg * every / steps}
         if every != timed:  # frames with more than 64 launches of the class: the untimed ones are taken at the timed average
             out[name]["launches_untimed"] = every - timed
+    if acc["tail_launches"]:
+        # the fused launch that runs what is left of the recursion once a level is small (closest hit, shadow rays and
+        # shading of every further level)
+        out["k_tail"] = {"launches": acc["tail_launches"], "avg_launch_ms": acc["tail_ms"] / acc["tail_launches"],
+                         "ms_per_frame": acc["tail_ms"] / steps}
     out["k_shadow"]["Mrays_per_s"] = shadow_rate / 1e6
     out["k_closest"]["Mrays_per_s"] = closest_rate / 1e6
     if work is not None:
@@ -151,7 +174,7 @@ def kernel_summary(acc, steps, work):
 
 
 def new_acc():
-    return dict(rays=0, shade_ms=0.0, closest_ms=0.0, shadow_ms=0.0, shade_launches=0, closest_launches=0, shadow_launches=0,
+    return dict(tail_ms=0.0, tail_launches=0, rays=0, shade_ms=0.0, closest_ms=0.0, shadow_ms=0.0, shade_launches=0, closest_launches=0, shadow_launches=0,
                 shade_launches_all=0, closest_launches_all=0, shadow_launches_all=0, shadow_rays=0, closest_rays=0)
 
 
@@ -165,6 +188,8 @@ def add_stats(acc, st):
     acc["shade_launches"] += min(st.launches_shade, 64)
     acc["shadow_launches"] += min(st.launches_shadow, 64)
     acc["closest_launches"] += min(st.launches_closest, 64)
+    acc["tail_ms"] += st.ms_tail
+    acc["tail_launches"] += st.launches_tail
     acc["shade_launches_all"] += st.launches_shade
     acc["shadow_launches_all"] += st.launches_shadow
     acc["closest_launches_all"] += st.launches_closest
@@ -505,6 +530,12 @@ def main():
             # reference work per ray, counted on the device in the reference's definitions (whole reduced frame)
             work = reference_work(ads, rt, wl)
             out["reference_work_per_ray"] = work
+        elif world == 1:
+            # a run without extra launches (the one that is profiled): the per-ray work is a constant of the workload --
+            # same scene, camera and generator -- and is quoted from the newest committed default run
+            work = committed_reference_work(args.workload)
+            if work is not None:
+                out["reference_work_per_ray"] = work
         # ---- CPU baselines on bounded samples of the same frame (rank 0, N = 1 only) ----
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             r0, r1 = wl["cpu_rows"]

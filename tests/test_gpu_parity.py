@@ -372,6 +372,72 @@ def test_both_traversals(rt, orc, scenes, monkeypatch, mode, scene, mb, md):
     assert np.abs(img - ref).max() <= 1.0 / 255.0
 
 
+def coplanar_layers_scene(orc, scenes):
+    """A plane of 32 x 32 unit cells (2 triangles each) covered by the same plane again in triangles with legs 8, 16 and
+    32 -- listed after the cells -- plus a little geometry above and below.  Every coordinate is a small
+    integer and every leg a power of two, so a ray with dyadic components meets all layers at bit-equal distances: the
+    winner is decided by the reference's list order alone, and the big triangles are listed by leaves far from the hit."""
+    def cover(n, z=0.0):
+        out = []
+        for i in range(0, 32, n):
+            for j in range(0, 32, n):
+                out += [[[i, j, z], [i + n, j, z], [i, j + n, z]], [[i + n, j + n, z], [i, j + n, z], [i + n, j, z]]]
+        return out
+    tris = cover(1) + cover(8) + cover(32) + cover(16)
+    tris += [[[3, 3, 6], [5, 3, 6], [3, 5, 6]], [[20, 20, -10], [28, 20, -10], [20, 28, -10]], [[0, 0, -10], [4, 0, -10], [0, 4, -10]]]
+    pos = np.asarray(tris, np.float32)
+    base = scenes["original"]
+    return orc.Scene.from_arrays(pos, None, np.zeros(pos.shape[0], base.matid.dtype), base.materials)
+
+
+def tie_rays(n, rs):
+    """Dyadic origins over the square, dyadic directions from steep to 1 : 16 shallow, from both sides of the plane."""
+    o = np.stack([rs.randint(0, 128, n) / 4.0, rs.randint(0, 128, n) / 4.0, rs.choice([4.0, 2.0, 1.0, -4.0], n)], axis=1).astype(np.float32)
+    steps = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, -3.0, 4.0, 0.25], np.float32)
+    d = np.stack([rs.choice(steps, n), rs.choice(steps, n), -np.sign(o[:, 2]) * rs.choice([1.0, 0.5, 0.25], n)], axis=1).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("mode", ["auto", "wave", "lane", "pool"])
+@pytest.mark.parametrize("clip", ["1", "0"])
+def test_pruned_walks_keep_the_tie_rule(rt, orc, scenes, monkeypatch, mode, clip):
+    """Closest-hit walks that stop following a ray beyond its best hit, and any-hit walks that cover the segment only,
+    must still name the triangle the reference's loop over the WHOLE candidate list names when several triangles are met
+    at the same distance (renderer.cc:130: the first one in list order) -- including when the first listing leaf lies
+    beyond the hit or behind the origin.  Every traversal form, clipped and unclipped, against the oracle; the scene makes
+    nearly every hit such a tie."""
+    monkeypatch.setenv("RT_CLIP", clip)
+    if mode != "auto":
+        monkeypatch.setenv("RT_TRAVERSAL", mode)
+        monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    sc = coplanar_layers_scene(orc, scenes)
+    for mb, md in ((8, 6), (16, 10)):
+        g = build(rt, sc, mb, md)
+        ot = orc.Octree(sc, mb, md)
+        rs = np.random.RandomState(23)
+        n = 6000
+        o, d = tie_rays(n, rs)
+        for cull in (False, True):
+            t_ref, tri_ref = ot.trace_closest(o, d, cull)
+            t, tri = g.trace_closest(o, d, cull)
+            assert np.array_equal(tri, tri_ref) and np.array_equal(bits(t), bits(t_ref))
+        # the ties are real and not trivially ordered: the plane is met inside the square by most rays, and the winner is
+        # neither always the lowest nor always the highest triangle index of the layers
+        t_ref, tri_ref = ot.trace_closest(o, d, False)
+        on_plane = (tri_ref >= 0) & (tri_ref < len(sc.pos) - 3)
+        assert on_plane.sum() > 2000
+        layer = np.bincount(np.digitize(tri_ref[on_plane], [2048, 2048 + 32, 2048 + 34]), minlength=4)
+        assert layer[0] > 300 and layer[1:].sum() > 300
+        # segments that end exactly on the plane (not occluded by it: renderer.cc:302 wants t < distance) or just beyond it
+        oo, P = o[on_plane], (o[on_plane] + d[on_plane] * t_ref[on_plane, None]).astype(np.float32)
+        beyond = (oo + (P - oo) * np.float32(1.25)).astype(np.float32)
+        short = (oo + (P - oo) * np.float32(0.75)).astype(np.float32)
+        for cull in (False, True):
+            for L in (P, beyond, short):
+                assert np.array_equal(ot.trace_any(oo, L, cull), g.trace_any(oo, L, cull))
+        assert ot.trace_any(oo, beyond, False).sum() > 1000 and ot.trace_any(oo, short, False).sum() < 100
+
+
 @pytest.mark.parametrize("scene,mb,md", [("original", 16, 10), ("sphere", 16, 10), ("sphere", 4, 3)])
 def test_search_candidate_lists(rt, orc, scenes, scene, mb, md):
     sc = scenes[scene]

@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-KERNELS = ("k_shadow", "k_closest", "k_shade", "k_resolve_pixels", "k_resolve", "k_roll_counters", "k_frame_begin")
+KERNELS = ("k_shadow", "k_closest", "k_shade", "k_tail", "k_resolve_pixels", "k_resolve", "k_roll_counters", "k_frame_begin")
 N_SIMD = 1024  # 256 CUs x 4 SIMDs
 
 
