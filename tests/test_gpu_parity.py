@@ -348,6 +348,7 @@ def test_both_traversals(rt, orc, scenes, monkeypatch, mode, scene, mb, md):
     turn and must each reproduce the oracle: closest hits, occlusion flags and a rendered frame with shadow and secondary rays."""
     monkeypatch.setenv("RT_TRAVERSAL", mode)
     monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    monkeypatch.setenv("RT_PRUNE_MIN_SLOTS", "0")  # (wave form: the pruned closest-hit walk, which trees this small do not get by default)
     sc = scenes[scene]
     g = build(rt, sc, mb, md)
     ot = orc.Octree(sc, mb, md)
@@ -407,6 +408,7 @@ def test_pruned_walks_keep_the_tie_rule(rt, orc, scenes, monkeypatch, mode, clip
     beyond the hit or behind the origin.  Every traversal form, clipped and unclipped, against the oracle; the scene makes
     nearly every hit such a tie."""
     monkeypatch.setenv("RT_CLIP", clip)
+    monkeypatch.setenv("RT_PRUNE_MIN_SLOTS", "0")  # (the wave-together closest-hit walk prunes on trees of any size)
     if mode != "auto":
         monkeypatch.setenv("RT_TRAVERSAL", mode)
         monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
@@ -477,6 +479,7 @@ def test_degenerate_rays_and_ragged_batches(rt, orc, scenes, monkeypatch, scene,
     if mode != "auto":
         monkeypatch.setenv("RT_TRAVERSAL", mode)
         monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+        monkeypatch.setenv("RT_PRUNE_MIN_SLOTS", "0")
     sc = scenes[scene]
     g = build(rt, sc)
     ot = orc.Octree(sc, 16, 10)
