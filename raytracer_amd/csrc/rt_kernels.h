@@ -706,11 +706,16 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
             }
             const f3 n_l = mk(L.n[0], L.n[1], L.n[2]);
             f3 acc = mk(0, 0, 0);
-            uint32_t bits = 0;
-            for (int s = 0; s < F.spt; ++s) {
-                if ((s & 31) == 0) bits = vis_word(l, (uint32_t)(s >> 5));
-                if (!((bits >> (s & 31)) & 1u)) continue;  // shadowed
-                const f3 p_l = light_sample(L, pre, l, (uint32_t)s);
+            // Every lane steps through ITS visible samples (ascending, so the sum keeps the reference's order): the wave
+            // takes as many turns as its lane with the most visible samples, not one per sample that any lane sees.
+            for (uint32_t wd = 0; wd * 32u < (uint32_t)F.spt; ++wd) {
+              uint32_t bits = vis_word(l, wd);
+              const uint32_t left = (uint32_t)F.spt - wd * 32u;
+              if (left < 32u) bits &= (1u << left) - 1u;
+              while (bits != 0) {
+                const uint32_t s = wd * 32u + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const f3 p_l = light_sample(L, pre, l, s);
                 // renderer.cc:220-240
                 const f3 to_l = p_l - P;
                 const float dist = length(to_l);
@@ -734,6 +739,7 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
                 f3 c = (I_a + I_d) + I_s;
                 if (F.render_type == 2) c = c + mk(m.emission[0], m.emission[1], m.emission[2]);  // renderer.cc:264-266
                 acc = acc + c;
+              }
             }
             final_c = final_c + acc;
         }
