@@ -88,8 +88,13 @@ __device__ __forceinline__ f3 reciprocal3(f3 d, bool need) {
     // component, and no caller lets a reciprocal reach an output -- it only feeds comparisons, which a NaN fails whatever
     // its sign and payload.
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    const float lo = __builtin_fminf(__builtin_fminf(ax == 0.0f ? 1.0f : ax, ay == 0.0f ? 1.0f : ay), az == 0.0f ? 1.0f : az);
     const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float lo_all = __builtin_fminf(__builtin_fminf(ax, ay), az);
+    if (__builtin_amdgcn_ballot_w64(need && lo_all == 0.0f) == 0) {  // no zero component in the wave: nothing to patch
+        if (__builtin_amdgcn_ballot_w64(need && !(lo_all >= kEps && hi <= kDivFastMax)) == 0) return f3{rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z)};
+        return f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    }
+    const float lo = __builtin_fminf(__builtin_fminf(ax == 0.0f ? 1.0f : ax, ay == 0.0f ? 1.0f : ay), az == 0.0f ? 1.0f : az);
     const bool in_range = lo >= kEps && hi <= kDivFastMax;
     if (__builtin_amdgcn_ballot_w64(need && !in_range) == 0) {
         const float ix = rcp_refined(d.x), iy = rcp_refined(d.y), iz = rcp_refined(d.z);
