@@ -397,12 +397,20 @@ uint32_t pool_sparse(const rt_ads* a, int mode, uint64_t n_rays, uint32_t max_gr
 // Threads per block of k_closest.  Its hit compaction costs one atomic per block and the whole block waits for its
 // slowest wave there: big blocks pay off where waves take similar, short times (small trees), not on big trees where
 // a wave over a finely tessellated region runs many times longer than its neighbours.
-uint32_t closest_block(const rt_ads* a, int mode) { return (mode == MODE_WAVE && a->n_slots < kWaveFormMaxSlots) ? 1024u : 256u; }
+// Closest-hit launches: the wave-together walk of a tree below prune_min_slots leaf slots is not pruned by the best hit
+// (see closest_opts).
+bool closest_prunes(const rt_ads* a, int mode) { return a->clip && !(mode == MODE_WAVE && a->n_slots < a->prune_min_slots); }
+uint32_t closest_block(const rt_ads* a, int mode) {
+    return (mode == MODE_WAVE && a->n_slots < kWaveFormMaxSlots && !closest_prunes(a, mode)) ? 1024u : 256u;
+}
 
 template <class... Args>
-void launch_closest(bool cull, int mode, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+void launch_closest(bool cull, int mode, bool prune, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
     const bool big = block.x > 256;
-    if (mode == MODE_POOL) {
+    if (mode == MODE_WAVE && prune) {  // (never with the big blocks of the small trees)
+        if (cull) hipLaunchKernelGGL((k_closest<true, MODE_WAVE_PRUNED, false>), grid, block, 0, stream, args...);
+        else hipLaunchKernelGGL((k_closest<false, MODE_WAVE_PRUNED, false>), grid, block, 0, stream, args...);
+    } else if (mode == MODE_POOL) {
         if (cull) hipLaunchKernelGGL((k_closest<true, MODE_POOL, false>), grid, block, 0, stream, args...);
         else hipLaunchKernelGGL((k_closest<false, MODE_POOL, false>), grid, block, 0, stream, args...);
     } else if (mode == MODE_LANE) {
@@ -431,10 +439,7 @@ uint32_t launch_opts(const rt_ads* a, uint32_t sparse) { return trace_opts(spars
 // Such a tree is a few levels deep, the union walk of a bundle opens most of it anyway, and the bookkeeping of the
 // pruned walk (ordered pushes, entry distances) then costs more than it saves: Cornell-Sphere's closest-hit passes take
 // 0.84 ms unpruned against 0.91 ms pruned.  The result is the same either way.
-uint32_t closest_opts(const rt_ads* a, int mode, uint32_t sparse) {
-    const bool prune = a->clip && !(mode == MODE_WAVE && a->n_slots < a->prune_min_slots);
-    return trace_opts(sparse, prune, tree_levels(a));
-}
+uint32_t closest_opts(const rt_ads* a, int mode, uint32_t sparse) { return trace_opts(sparse, closest_prunes(a, mode), tree_levels(a)); }
 size_t lane_lds(const rt_ads* a, int mode, uint32_t block_threads, bool closest) {
     return mode == MODE_LANE ? (size_t)(block_threads / 64u) * lane_stack_words(tree_levels(a), closest) * sizeof(uint32_t) : 0;
 }
@@ -1252,8 +1257,13 @@ int rt_ads_trace_closest(rt_ads* a, const float* origins, const float* dirs, uin
     const int mode = traversal_mode(a, false, false, n);
     const uint32_t sparse = pool_sparse(a, mode, n, 1);
     const dim3 block(256), grid((unsigned)((mode_threads(mode, n, sparse) + 255) / 256));
-    RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, lane_lds(a, mode, block.x, true), stream, dev_tree(a), d_o, d_d, n, d_t, d_tri,
-               closest_opts(a, mode, sparse));
+    if (mode == MODE_WAVE && closest_prunes(a, mode)) {
+        if (cull) hipLaunchKernelGGL((k_trace_closest<true, MODE_WAVE_PRUNED>), grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, closest_opts(a, mode, sparse));
+        else hipLaunchKernelGGL((k_trace_closest<false, MODE_WAVE_PRUNED>), grid, block, 0, stream, dev_tree(a), d_o, d_d, n, d_t, d_tri, closest_opts(a, mode, sparse));
+    } else {
+        RT_LAUNCH2(k_trace_closest, cull != 0, mode, grid, block, lane_lds(a, mode, block.x, true), stream, dev_tree(a), d_o, d_d, n, d_t, d_tri,
+                   closest_opts(a, mode, sparse));
+    }
     HIP_TRY(hipGetLastError());
     if (a->collect_stats) {
         if (int rc = stats_begin(a, stream)) return rc;
@@ -1667,7 +1677,7 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
             const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, cap, sparse_c) + block_c.x - 1) / block_c.x));
             if (int rc = mark(CLS_CLOSEST)) return rc;
             const bool timed_c = last_timed;
-            launch_closest(F.cull != 0, mode_c, grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, S, F, L, lv.rays.p, cap, lv.hit_t.p,
+            launch_closest(F.cull != 0, mode_c, closest_prunes(a, mode_c), grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, S, F, L, lv.rays.p, cap, lv.hit_t.p,
                            lv.hit_tri.p, lv.out.p, lv.work.p, cnt, closest_opts(a, mode_c, sparse_c));
             HIP_TRY(hipGetLastError());
             st.launches_closest++;
@@ -1929,7 +1939,7 @@ int rt_render_primary_hits(rt_ads* a, const rt_render_config* c, float* out_t, i
     const int mode_c = traversal_mode(a, true, false, n0);
     const uint32_t sparse_c = pool_sparse(a, mode_c, n0, 1);
     const dim3 block_c(closest_block(a, mode_c)), grid_c((uint32_t)((mode_threads(mode_c, n0, sparse_c) + block_c.x - 1) / block_c.x));
-    launch_closest(F.cull != 0, mode_c, grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0,
+    launch_closest(F.cull != 0, mode_c, closest_prunes(a, mode_c), grid_c, block_c, lane_lds(a, mode_c, block_c.x, true), stream, scene_dev(a), F, 0u, (const RayRec*)nullptr, n0,
                    lv.hit_t.p, lv.hit_tri.p, lv.out.p, lv.work.p, x.d_counters.p, closest_opts(a, mode_c, sparse_c));
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_primary_hits, grid, block, 0, stream, F, lv.hit_t.p, lv.hit_tri.p, n0, d_t, d_tri);

@@ -22,7 +22,7 @@
 #define RT_SHADOW_WAVES 0
 #endif
 #if RT_CLOSEST_WAVES
-#define RT_CLOSEST_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu((MODE) == 0 ? RT_CLOSEST_WAVES : 4, 8)))
+#define RT_CLOSEST_OCCUPANCY(MODE) __attribute__((amdgpu_waves_per_eu(((MODE) == 0 || (MODE) == 4) ? RT_CLOSEST_WAVES : 4, 8)))
 #else
 #define RT_CLOSEST_OCCUPANCY(MODE)
 #endif
@@ -50,7 +50,7 @@ namespace rt {
 // per-wave stacks of the last two are in LDS; a kernel declares one slot per wave of its block.  MODE_CLUSTER: the wave
 // together over the clustered form of the tree (any-hit kernels only; a kernel of its own so that its extra registers
 // do not cost the other wave-together kernels their occupancy).
-enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_POOL = 2, MODE_CLUSTER = 3 };
+enum { MODE_WAVE = 0, MODE_LANE = 1, MODE_POOL = 2, MODE_CLUSTER = 3, MODE_WAVE_PRUNED = 4 };
 template <int MODE>
 struct TraverseLds {
     uint32_t unused;
@@ -102,7 +102,11 @@ __device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds
         static_assert(ANY, "the clustered form serves any-hit queries");
         traverse_any_clustered<CULL, FAST>(T, valid, o, d, t_limit, clip, h);
     } else {
-        traverse<ANY, CULL, FAST>(T, valid, o, d, t_limit, clip, h);
+        // Closest-hit walks of the wave are pruned by the best hit only in an instantiation of their own
+        // (MODE_WAVE_PRUNED, closest-hit kernels only): the ordered, pruned walk more than doubles the kernel's code, and
+        // the small trees that MODE_WAVE serves by default never use it.
+        static_assert(MODE != MODE_WAVE_PRUNED || !ANY, "");
+        traverse<ANY, CULL, FAST>(T, valid, o, d, t_limit, ANY ? clip : (MODE == MODE_WAVE_PRUNED), h);
     }
 }
 

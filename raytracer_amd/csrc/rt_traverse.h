@@ -335,7 +335,8 @@ __device__ __forceinline__ Block48 sload48(cu32_p p) {
 constexpr int kTriChunk = 4;  // triangle records per scalar-load group (arrays are padded by this many records)
 
 // One record of a leaf's 4-record block (record j, global slot `slot`) for the lanes in `mine`.
-template <bool ANY, bool CULL, bool FAST = false>
+// TIE (closest hit, pruned walks): also note the lanes whose best distance is met by two distinct triangles.
+template <bool ANY, bool CULL, bool FAST = false, bool TIE = false>
 __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32_t slot, lanemask mine, f3 o, f3 d, float t_limit,
                                          HitState& h) {
     if (mine == 0) return;
@@ -361,7 +362,7 @@ __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32
         const uint32_t tri = RT_W(blk, 12 * j + 9);
         // Two distinct triangles at the best distance: which one the reference takes depends on every leaf that lists
         // them, also on leaves a pruned walk leaves out -- such rays are walked again without pruning (traverse<>).
-        h.tie = (h.tie & ~less) | (same_t & ballot64(tri != h.tri));
+        if (TIE) h.tie = (h.tie & ~less) | (same_t & ballot64(tri != h.tri));
         if (better == 0) return;
         const bool b = lane_of(better);
         h.t = b ? t : h.t;
@@ -372,17 +373,17 @@ __device__ __forceinline__ void leaf_one(const Block48& blk, const int j, uint32
 
 // Tests the triangles of leaf slots [begin, begin+count) for the lanes in `mine`.  Records are read four at a time;
 // those past the leaf's end (the next leaf's, or the array's padding) get an empty lane mask.
-template <bool ANY, bool CULL, bool FAST = false>
+template <bool ANY, bool CULL, bool FAST = false, bool TIE = false>
 __device__ __forceinline__ void leaf_tests(const DevOctree& T, uint32_t begin, uint32_t count, lanemask mine, f3 o, f3 d, float t_limit,
                                            HitState& h) {
     cu32_p base = as_const_u(T.slots);
     for (uint32_t k0 = 0; k0 < count; k0 += kTriChunk) {
         const Block48 blk = sload48(base + (size_t)(begin + k0) * 12);
         const lanemask none = 0;
-        leaf_one<ANY, CULL, FAST>(blk, 0, begin + k0 + 0, ANY ? (mine & ~h.found) : mine, o, d, t_limit, h);
-        leaf_one<ANY, CULL, FAST>(blk, 1, begin + k0 + 1, k0 + 1 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
-        leaf_one<ANY, CULL, FAST>(blk, 2, begin + k0 + 2, k0 + 2 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
-        leaf_one<ANY, CULL, FAST>(blk, 3, begin + k0 + 3, k0 + 3 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST, TIE>(blk, 0, begin + k0 + 0, ANY ? (mine & ~h.found) : mine, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST, TIE>(blk, 1, begin + k0 + 1, k0 + 1 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST, TIE>(blk, 2, begin + k0 + 2, k0 + 2 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
+        leaf_one<ANY, CULL, FAST, TIE>(blk, 3, begin + k0 + 3, k0 + 3 < count ? (ANY ? (mine & ~h.found) : mine) : none, o, d, t_limit, h);
         if (ANY && (mine & ~h.found) == 0) return;  // every ray that reached this leaf is decided
     }
 }
@@ -556,11 +557,10 @@ __device__ __forceinline__ bool octant_passes(const SlabSides& s, const int c, f
 }
 
 // valid: this lane carries a ray.  For ANY, t_limit is the distance to the light.
-// sp: the part of the ray whose boxes are walked.  prune (closest hit): the upper bound follows the best distance.
+// sp: the part of the ray whose boxes are walked (closest-hit walks that follow their best hit: traverse_packet_pruned).
 template <bool ANY, bool CULL, bool FLAT, bool FAST = false>
-__device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, Span sp, bool prune, HitState& h) {
+__device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, f3 o, f3 d, float t_limit, Span sp, HitState& h) {
     const f3 inv = reciprocal3(d, lane_of(all));  // collision_detection.h:76
-    const float pad_abs = span_pad_abs(o);
     WaveStack st;
     uint32_t reach = 0;
     cu32_p nodes = as_const_u(FLAT ? T.flat_nodes : T.nodes);
@@ -576,12 +576,11 @@ __device__ __forceinline__ void traverse_impl(const DevOctree& T, lanemask all, 
             const u32x16 info = sload16(rec + 16);  // dwords 16..31 = info[8][2]
             SlabSides sl;
             slab_sides(pl, o, inv, sl);
-            const float hi = (!ANY && prune) ? span_hi_closest(h.t, pad_abs) : sp.hi;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t c1 = info[2 * c + 1];
                 if (c1 == 0) continue;  // null or empty octant (octree.cc:195)
-                const lanemask pm = mine & ballot64(octant_passes(sl, c, sp.lo, hi));
+                const lanemask pm = mine & ballot64(octant_passes(sl, c, sp.lo, sp.hi));
                 if (pm == 0) continue;
                 if (FLAT && !(c1 & kChildInternal)) reach |= lane_of(pm) ? (1u << info[2 * c]) : 0u;
                 else st.push(info[2 * c], c1, pm);
@@ -699,7 +698,7 @@ __device__ __forceinline__ void traverse_packet_pruned(const DevOctree& T, lanem
                 default: push_octants_ordered<7>(sl, info, mine, lo, hi, st); break;
             }
         } else {
-            leaf_tests<false, CULL, false>(T, i0, i1, mine, o, d, 0.0f, h);
+            leaf_tests<false, CULL, false, true>(T, i0, i1, mine, o, d, 0.0f, h);
         }
         // next entry that some lane can still gain from: a lane whose best hit is nearer than the entry's nearest point is out
         bool got = false;
@@ -849,29 +848,28 @@ __device__ __forceinline__ void traverse(const DevOctree& T, bool valid, f3 o, f
     // A root that is a leaf makes every triangle a candidate without any box test (octree.cc:56-63,186-191);
     // traverse_impl handles it as a leaf entry.
     if (T.n_flat_tris) {  // (a tree of at most 32 leaves: its walk is one node or a few, nothing worth clipping)
-        traverse_impl<ANY, CULL, true, FAST>(T, all, o, d, t_limit, span_all(), false, h);
+        traverse_impl<ANY, CULL, true, FAST>(T, all, o, d, t_limit, span_all(), h);
         return;
     }
     if (ANY) {
-        traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, span_segment(o, t_limit, clip), false, h);
+        traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, span_segment(o, t_limit, clip), h);
         return;
     }
-    lanemask todo = all;
-    bool pruned = clip;
-#pragma nounroll
-    for (;;) {
-        HitState w;
-        hit_state_reset(w);
-        if (pruned) traverse_packet_pruned<CULL>(T, todo, o, d, span_lo_closest(o, true), w);
-        else traverse_impl<ANY, CULL, false, FAST>(T, todo, o, d, t_limit, span_all(), false, w);
-        const bool mine = lane_of(todo);
-        h.t = mine ? w.t : h.t;
-        h.slot = mine ? w.slot : h.slot;
-        h.tri = mine ? w.tri : h.tri;
-        if (!pruned || w.tie == 0) break;
-        todo = w.tie;
-        pruned = false;
+    if (!clip) {
+        traverse_impl<ANY, CULL, false, FAST>(T, all, o, d, t_limit, span_all(), h);
+        return;
     }
+    traverse_packet_pruned<CULL>(T, all, o, d, span_lo_closest(o, true), h);
+    if (h.tie == 0) return;
+    // the rays whose best distance two distinct triangles share: once more, like the reference walks them
+    const lanemask again = h.tie;
+    HitState w;
+    hit_state_reset(w);
+    traverse_impl<ANY, CULL, false, FAST>(T, again, o, d, t_limit, span_all(), w);
+    const bool redo = lane_of(again);
+    h.t = redo ? w.t : h.t;
+    h.slot = redo ? w.slot : h.slot;
+    h.tri = redo ? w.tri : h.tri;
 }
 
 // Any-hit query over the clustered form (T.cl_nodes must be set; the host launches this only for such trees).
