@@ -187,3 +187,40 @@ def test_large_tree_4k_frame_properties(rt, orc, monkeypatch):
     ref, _, _, ost = orc.render(osc, orc.Octree(osc, 16, 10),
                                 orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(1000, 1002), **{**kw, "aspect_mode": orc.ASPECT_TRUE}), want_hits=False)
     assert np.abs(frames["auto"][0][1000:1002] - ref[1000:1002]).max() <= 1.0 / 255.0
+
+
+# ---- how a frame is scheduled must not show in it -----------------------------------------------------------------------
+
+def test_fused_tail_and_sub_frames_leave_the_frame_unchanged(rt, monkeypatch):
+    """A big-tree frame whose paths are chains (no material reflects AND transmits) may run the small deep levels of
+    its recursion as one fused launch, and any frame may be split into concurrent sub-frames.  Neither may change a bit
+    of the image, a ray count or the depth reached: level by level, fused from the first level that qualifies, fused from
+    level 1 on, and 3 / 8 sub-frames with and without the fused launch all give the same frame."""
+    from test_gpu_parity import synthetic_scene
+    s = synthetic_scene(6)  # 81,954 triangles: per-lane form
+    kw = dict(fov=0.6, width=960, height=540, spt=1, render_type="phong", shading="flat", aspect_mode=1, **CAMERAS["original"])
+    cfg = rt.make_render_config(**kw)
+
+    def frame(tail_max_rays, streams):
+        if tail_max_rays is None:
+            monkeypatch.delenv("RT_TAIL_MAX_RAYS", raising=False)
+        else:
+            monkeypatch.setenv("RT_TAIL_MAX_RAYS", str(tail_max_rays))
+        g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+        g.Build(s.pos)
+        g.set_shading(None, s.matid, s.materials)
+        g.set_render_streams(streams)
+        img, st = g.render(cfg)
+        g.close()
+        return img, st
+
+    ref, st0 = frame(0, 1)
+    assert st0.launches_tail == 0 and st0.levels >= 5 and st0.secondary_rays > 10000
+    for tail, streams in ((None, 1), (1 << 30, 1), (20000, 1), (0, 3), (None, 3), (1 << 30, 8)):
+        img, st = frame(tail, streams)
+        assert np.array_equal(bits(img), bits(ref)), (tail, streams)
+        assert (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays, st.levels) == \
+               (st0.rays, st0.primary_rays, st0.secondary_rays, st0.shadow_rays, st0.levels), (tail, streams)
+        assert (st.launches_tail > 0) == (tail != 0), (tail, streams)
+        if tail == 1 << 30 and streams == 1:
+            assert st.launches_closest == 1  # level 0 only: everything below ran in the fused launch
