@@ -9,7 +9,11 @@ HBM.  For N > 1 there is one rank per GPU (started by torch.distributed.run, or 
 when it is called as plain `python bench.py --gpus N`): the image is cut into bands of 8 pixel rows
 dealt round-robin to the ranks, the scene is replicated, and the bands are gathered to rank 0 over
 RCCL inside the timed region (the gather of a frame overlaps the rendering of the next one; all of
-them are complete before the clock stops); the total work is fixed ("strong" scaling).
+them are complete before the clock stops); the total work is fixed ("strong" scaling).  With N > 1 a rank keeps
+several frames in flight (rt_render_submit / rt_render_wait, FRAMES_IN_FLIGHT): its share of a frame is a short chain of
+dependent launches that cannot fill a GPU by itself.  With N = 1 the timed loop is one blocking rt_render per frame (the
+per-kernel times are then those of kernels running alone) and the rate with frames in flight is reported beside it
+(`frames_in_flight`).
 
 Prints ONE JSON line on rank 0.  metric = Mrays/s, one ray = one Search-equivalent query of the
 reference (primary, secondary or shadow).
@@ -36,6 +40,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Frames in flight run on streams of the library's own; the HIP runtime maps streams onto this many hardware queues
+# (its default is 4, which serialises pairs of them).  Read when the runtime starts, so it is set before torch is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CAM_ORIGINAL = dict(cam_pos=[278.0, 273.0, -1000.0], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=2000.0)
 CAM_SPHERE = dict(cam_pos=[0.0, 1.0, 4.42], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, -1.0], max_distance=6.0)
@@ -56,12 +63,13 @@ WORKLOADS = {
     # fuzzysampling (64 samples per pixel) + 32 samples per light, 4K
     "cornell_original_blinn_spp64_spt32_4k": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong",
-        shading="flat", cull=True, max_depth=10, cpu_rows=(1080, 1082)),
+        shading="flat", cull=True, max_depth=10, cpu_rows=(1080, 1082), in_flight=2),
     # a small case for quick checks
     "cornell_original_blinn_spt4_256": dict(
         scene="cornell_original", cam=CAM_ORIGINAL, width=256, height=256, spp=1, spt=4, render_type="blinn_phong",
         shading="flat", cull=True, max_depth=10, cpu_rows=(96, 160)),
 }
+# "in_flight": frames in flight of the pipelined loops if not FRAMES_IN_FLIGHT (a frame of a second fills the GPU alone)
 # "streams": sub-frames a rt_render call of the workload runs concurrently (rt_ads_set_render_streams); pays where a frame
 # is a long chain of small recursion levels
 DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
@@ -69,6 +77,17 @@ DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
 OTHER_WORKLOADS = {"cornell_sphere_blinn_smooth_spp4_1080p": 4, "synthetic_ico8_phong_4k": 5, "cornell_original_blinn_spp64_spt32_4k": 2}
 # ... and the ones a multi-GPU run appends (band-split over the ranks): the workloads the scaling target names
 OTHER_WORKLOADS_MULTI = {"synthetic_ico8_phong_4k": 6, "cornell_original_blinn_spp64_spt32_4k": 2}
+
+# Frames in flight (rt_render_submit / rt_render_wait) of the pipelined loops: with N > 1 for `value` (a rank's share of a
+# frame is a short chain of launches that cannot fill the GPU alone), with N = 1 reported beside the blocking loop.
+# Measured on one MI355X with 8 hardware queues: 4 is best or within 1 % of it for every workload and split.
+FRAMES_IN_FLIGHT = int(os.environ.get("RT_BENCH_IN_FLIGHT") or 4)
+
+
+
+def depth_for(wl):
+    return min(FRAMES_IN_FLIGHT, wl.get("in_flight", FRAMES_IN_FLIGHT))
+
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 FP32_NO_FMA_PEAK_TOPS = 78.6      # the same lanes issuing one non-fused op per clock (bit-parity forbids FMA)
@@ -243,38 +262,64 @@ def build_ads(rt, scene, wl, device=0):
 class FrameLoop:
     """Renders frames of one workload on this rank's bands and moves them to rank 0.
 
-    Two frame buffers: while the bands of one frame travel to rank 0 (RCCL, on its own stream), the next frame is
-    rendered into the other buffer.  overlap=False completes every gather before the next frame starts.  The gathers
+    A ring of frame buffers: while the bands of one frame travel to rank 0 (RCCL, on its own stream), the next frame is
+    rendered into another buffer.  overlap=False completes every gather before the next frame starts.  The gathers
     run on a worker thread with its own stream (use_thread=False: on the calling thread, between the frames): the
     renderer's call only returns when its frame is complete, so whatever the calling thread does between two calls --
-    the host side of the collective included -- would otherwise add to every frame."""
+    the host side of the collective included -- would otherwise add to every frame.
 
-    def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True):
+    depth > 0: that many frames are in flight on the GPU (rt_render_submit / rt_render_wait); a frame is handed to the
+    gather when it is retired.  depth = 0: one blocking rt_render call per frame."""
+
+    def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True, depth=0):
         from raytracer_amd import distributed as rd
         self.ads, self.torch, self.dist = ads, torch, dist
         self.H, self.W = wl["height"], wl["width"]
         self.cfg = rt.make_render_config(band_rank=rank, band_world=world, **render_kwargs(wl))
-        self.frames = [rd.alloc_frame(self.H, self.W, world, "cuda") for _ in range(2)]
+        self.depth = depth if overlap or dist is None else 0
+        nbuf = 2 if self.depth == 0 else self.depth + 2
+        self.frames = [rd.alloc_frame(self.H, self.W, world, "cuda") for _ in range(nbuf)]
         self.stream = torch.cuda.current_stream().cuda_stream
-        self.gathers = [rd.BandGather(self.H, self.W, rank, world, "cuda", dist) for _ in range(2)]
+        self.gathers = [rd.BandGather(self.H, self.W, rank, world, "cuda", dist) for _ in range(nbuf)]
         self.overlap = dist is not None and overlap
         self.worker = rd.GatherThread(self.frames, self.gathers) if self.overlap and use_thread else None
         self.n = 0
+        self.in_flight = []  # (ticket, buffer) of the frames submitted and not yet retired, oldest first
 
-    def step(self):
-        k = self.n & 1
+    def _claim(self):
+        """The next buffer of the ring, once its previous frame has arrived on rank 0."""
+        k = self.n % len(self.frames)
         self.n += 1
         if self.worker is not None:
-            self.worker.wait(k)  # this buffer's previous frame must have arrived before it is overwritten
-            _, st = self.ads.render(self.cfg, out_ptr=self.frames[k].data_ptr(), stream=self.stream)
-            self.worker.submit(k)  # framebuffer bands -> rank 0
-            return st
-        self.gathers[k].finish()
-        _, st = self.ads.render(self.cfg, out_ptr=self.frames[k].data_ptr(), stream=self.stream)
+            self.worker.wait(k)
+        else:
+            self.gathers[k].finish()
+        return k
+
+    def _hand_over(self, k):
+        """Buffer k holds a complete frame: its bands start travelling to rank 0."""
+        if self.worker is not None:
+            self.worker.submit(k)
+            return
         self.gathers[k].start(self.frames[k])  # no-op for one rank
         if not self.overlap:
             self.gathers[k].finish()
+
+    def _retire(self):
+        ticket, k = self.in_flight.pop(0)
+        st = self.ads.render_wait(ticket)
+        self._hand_over(k)
         return st
+
+    def step(self):
+        """One frame, complete on return (its gather may still travel)."""
+        k = self._claim()
+        if self.depth == 0:
+            _, st = self.ads.render(self.cfg, out_ptr=self.frames[k].data_ptr(), stream=self.stream)
+            self._hand_over(k)
+            return st
+        self.in_flight.append((self.ads.render_submit(self.cfg, self.frames[k].data_ptr(), self.stream), k))
+        return self._retire()
 
     def fence(self):
         if self.worker is not None:
@@ -290,17 +335,36 @@ class FrameLoop:
         """Seconds for `steps` frames between two fences (barrier + device synchronisation on both sides)."""
         self.fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            st = self.step()
-            if acc is not None:
-                add_stats(acc, st)
+        if self.depth == 0:
+            for _ in range(steps):
+                st = self.step()
+                if acc is not None:
+                    add_stats(acc, st)
+        else:
+            for i in range(steps + self.depth):
+                if len(self.in_flight) == self.depth or i >= steps:
+                    if not self.in_flight:
+                        break
+                    st = self._retire()
+                    if acc is not None:
+                        add_stats(acc, st)
+                if i < steps:
+                    k = self._claim()
+                    self.in_flight.append((self.ads.render_submit(self.cfg, self.frames[k].data_ptr(), self.stream), k))
         self.fence()
         return time.perf_counter() - t0
 
+    def warm(self, frames=1):
+        """Untimed frames through the same loop.  Every frame slot of the library allocates its level buffers on its first
+        frame, so a loop with frames in flight is warm only after each slot has rendered one."""
+        self.timed(max(frames, 2 * self.depth))
+
     def last_frame(self):
-        return self.frames[(self.n - 1) & 1]
+        return self.frames[(self.n - 1) % len(self.frames)]
 
     def close(self):
+        while self.in_flight:
+            self._retire()
         if self.worker is not None:
             self.worker.close()
             self.worker = None
@@ -353,8 +417,8 @@ def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=Non
     wl = WORKLOADS[name]
     scene = load_scene(wl, Scene)
     ads = build_ads(rt, scene, wl, device=torch.cuda.current_device())
-    loop = FrameLoop(ads, rt, wl, rank, world, dist, torch)
-    loop.step()
+    loop = FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=depth_for(wl) if dist is not None else 0)
+    loop.warm()
     acc = new_acc()
     elapsed = max_over_ranks(loop.timed(frames, acc), dist, torch)
     rays = sum_over_ranks(acc["rays"], dist, torch)
@@ -365,6 +429,7 @@ def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=Non
            "octree_build_s": round(ts["build_seconds"], 4), "render_streams": int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)),
            "n_gpus": world}
     if dist is not None:
+        res["frames_in_flight"] = loop.depth
         # the same frames one after the other: rendering, gather and interleaving copy of a frame complete before the next
         # one starts -- the latency from the first launch to the frame resident on rank 0
         sync = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=False)
@@ -387,6 +452,16 @@ def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=Non
             one.close()
         else:
             frames_k = frames
+        # the same frames with several in flight (what a multi-GPU run uses for its shares)
+        if FRAMES_IN_FLIGHT > 0 and res["ms_per_frame"] < 200.0:  # (a frame of hundreds of milliseconds fills the GPU by itself)
+            ads.set_render_streams(1)
+            fl = FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=FRAMES_IN_FLIGHT)
+            fl.warm()
+            facc = new_acc()
+            n_fl = max(frames, 2 * FRAMES_IN_FLIGHT)
+            fl_s = fl.timed(n_fl, facc)
+            fl.close()
+            res["in_flight"] = {"depth": FRAMES_IN_FLIGHT, "frames": n_fl, "ms_per_frame": fl_s / n_fl * 1e3, "Mrays_per_s": facc["rays"] / fl_s / 1e6}
         work = reference_work(ads, rt, wl)
         ks = kernel_summary(acc, frames_k, work)
         memory_side(ks, name, name)
@@ -433,6 +508,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed frames: no reference-work pass, no other workloads, no host-framebuffer timing (counter passes)")
     ap.add_argument("--no-other-workloads", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="frames in flight of the timed loop (rt_render_submit / rt_render_wait); default: 0 = one blocking rt_render per "
+                         "frame with one GPU, %d with more" % FRAMES_IN_FLIGHT)
     args = ap.parse_args()
 
     # RT_BENCH_SELF_LAUNCH=1 takes the self-launch path with one rank too (a check of it on a one-GPU box)
@@ -478,15 +556,31 @@ def main():
     aspect = kw["aspect_mode"]
     cfg = rt.make_render_config(band_rank=rank, band_world=world, **kw)
 
+    depth = args.frames_in_flight if args.frames_in_flight is not None else (depth_for(wl) if dist is not None else 0)
+    if depth < 0 or depth > 8:
+        raise SystemExit("--frames-in-flight must be in 0..8")
     loop = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=os.environ.get("RT_BENCH_SYNC_GATHER") != "1",
-                     use_thread=os.environ.get("RT_BENCH_GATHER_THREAD") != "0")
-    for _ in range(args.warmup):
-        loop.step()
+                     use_thread=os.environ.get("RT_BENCH_GATHER_THREAD") != "0", depth=depth)
+    depth = loop.depth
+    loop.warm(args.warmup)
     acc = new_acc()
     elapsed = max_over_ranks(loop.timed(args.steps, acc), dist, torch)
     rays = sum_over_ranks(acc["rays"], dist, torch)
     frame = loop.last_frame()
     loop.close()
+    in_flight = None
+    if world == 1 and dist is None and depth == 0 and FRAMES_IN_FLIGHT > 0 and not args.no_extras:
+        # the same frames with several in flight: what a sequence of frames renders at when the caller does not wait for
+        # each one (reported beside `value`, which stays one blocking call per frame so that the per-kernel times of the
+        # timed region are those of kernels running alone)
+        fl = FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=FRAMES_IN_FLIGHT)
+        fl.warm(args.warmup)
+        facc = new_acc()
+        fl_s = fl.timed(args.steps, facc)
+        fl.close()
+        in_flight = {"depth": FRAMES_IN_FLIGHT, "frames": args.steps, "ms_per_frame": fl_s / args.steps * 1e3,
+                     "Mrays_per_s": facc["rays"] / fl_s / 1e6,
+                     "note": "rt_render_submit / rt_render_wait: the same frames, bit-identical images, %d in flight" % FRAMES_IN_FLIGHT}
     unoverlapped_ms = None
     if dist is not None:
         sync = FrameLoop(ads, rt, wl, rank, world, dist, torch, overlap=False)
@@ -517,8 +611,11 @@ def main():
                        "samples_per_triangle": wl["spt"], "render_type": wl["render_type"], "shading": wl["shading"],
                        "octree": "max_triangles_per_BB=16,max_depth=10", "aspect_mode": "true" if aspect else "compat",
                        "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3),
-                       "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)"},
+                       "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)",
+                       "frames_in_flight": depth},
         }
+        if in_flight is not None:
+            out["frames_in_flight"] = in_flight
         if unoverlapped_ms is not None:
             # `value` is the pipelined rate (the gather of a frame overlaps the rendering of the next); this is one frame
             # from its first launch to the framebuffer resident on rank 0, nothing overlapped
@@ -634,6 +731,10 @@ def main():
                     roof["lds_bank_conflict_frac"] = k.get("lds_bank_conflict_frac")
                     roof["counters_source"] = src + " (rocprofv3 --pmc SQ_* passes, per-launch means; valu_issue_frac divides the executed wave64 " \
                                                     "VALU lane-ops by this run's kernel time and the 78.6 T lane-ops/s issue peak)"
+        if depth > 0:
+            roof["kernel_times_note"] = ("frames in flight overlap: a kernel's event interval includes the kernels of other frames that ran "
+                                         "beside it, so these per-kernel figures are lower bounds of the kernels' own rates (the N = 1 run "
+                                         "times its kernels one frame at a time)")
         out["roofline"] = roof
         if world == 1 and not args.no_extras and not args.no_other_workloads and args.workload == DEFAULT_WORKLOAD:
             others = {}

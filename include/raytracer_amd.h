@@ -240,6 +240,20 @@ int rt_render(rt_ads* ads, const rt_render_config* cfg, float* out_rgb, int mem,
  * (Renderer::RenderScene, renderer.cc:37-52, is one sequential loop). */
 int rt_ads_set_render_streams(rt_ads* ads, int n);
 
+/* Frames in flight.  rt_render returns when its frame is complete, so a caller that renders a sequence of frames (or,
+ * with several GPUs, its bands of each) leaves the GPU to one frame at a time -- and a short frame is a chain of
+ * launches that each last as long as their slowest wavefront.  rt_render_submit queues a frame and returns at once with a
+ * ticket; up to 8 frames may be in flight per handle, each with its own level buffers, stream and host thread of the
+ * library (the host side of a frame sizes every recursion level from totals the kernels publish).  The frame starts
+ * behind what `stream` holds at the call.  rt_render_wait blocks until that frame is complete in out_rgb_device (device
+ * memory, height x width x 3 floats, only this call's bands written), returns its statistics and frees the ticket.
+ * Frames in flight must write different buffers or different bands; the image of a frame is the one rt_render gives.
+ * RT_ERR_CAPACITY when 8 frames are in flight already; RT_ERR_UNSUPPORTED while rt_ads_collect_search_stats is on.
+ * Calls on one handle come from one thread at a time.  No reference counterpart (Renderer::RenderScene,
+ * renderer.cc:37-52, renders one frame per process). */
+int rt_render_submit(rt_ads* ads, const rt_render_config* cfg, float* out_rgb_device, void* stream, int* ticket);
+int rt_render_wait(rt_ads* ads, int ticket, rt_render_stats* stats);
+
 /* Primary-ray closest hits only (sample 0, no shading): per pixel t and triangle index. */
 int rt_render_primary_hits(rt_ads* ads, const rt_render_config* cfg, float* out_t, int32_t* out_tri, int mem, void* stream);
 

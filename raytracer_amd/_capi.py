@@ -71,7 +71,7 @@ class RenderStats(C.Structure):
 EXPORTS = [
     "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_forms", "rt_ads_tree_stats",
     "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_search_noalloc", "rt_ads_trace_closest", "rt_ads_trace_any",
-    "rt_scene_set_shading", "rt_render", "rt_ads_set_render_streams", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
+    "rt_scene_set_shading", "rt_render", "rt_render_submit", "rt_render_wait", "rt_ads_set_render_streams", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
     "rt_host_tree_export_flat", "rt_host_tree_export_clustered", "rt_host_tree_stats",
     "rt_debug_triangle_tests", "rt_scene_load_obj", "rt_scene_data_free", "rt_scene_data_sizes", "rt_scene_data_export", "rt_write_ppm",
@@ -114,6 +114,8 @@ def lib():
     L.rt_ads_trace_any.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp]
     L.rt_scene_set_shading.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.rt_render.argtypes = [vp, C.POINTER(RenderConfig), vp, C.c_int, C.POINTER(RenderStats), vp]
+    L.rt_render_submit.argtypes = [vp, C.POINTER(RenderConfig), vp, vp, C.POINTER(C.c_int)]
+    L.rt_render_wait.argtypes = [vp, C.c_int, C.POINTER(RenderStats)]
     L.rt_render_primary_hits.argtypes = [vp, C.POINTER(RenderConfig), vp, vp, C.c_int, vp]
     L.rt_ads_set_render_streams.argtypes = [vp, C.c_int]
     L.rt_debug_triangle_tests.argtypes = [C.c_int, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_int, vp]

@@ -173,6 +173,18 @@ class GpuOctree(Ads):
         _capi.check(_capi.lib().rt_render(self._h, C.byref(cfg), _p(out), _capi.RT_MEM_HOST, C.byref(st), stream))
         return out, st
 
+    def render_submit(self, cfg, out_ptr, stream=None):
+        """Queues a frame into the device buffer at out_ptr and returns a ticket at once (up to 8 frames in flight)."""
+        ticket = C.c_int()
+        _capi.check(_capi.lib().rt_render_submit(self._h, C.byref(cfg), out_ptr, stream, C.byref(ticket)))
+        return ticket.value
+
+    def render_wait(self, ticket):
+        """Blocks until the frame of `ticket` is complete; returns its statistics."""
+        st = _capi.RenderStats()
+        _capi.check(_capi.lib().rt_render_wait(self._h, int(ticket), C.byref(st)))
+        return st
+
     def set_render_streams(self, n):
         """render() calls render their bands as n concurrent sub-frames on streams of the library's own (same image)."""
         _capi.check(_capi.lib().rt_ads_set_render_streams(self._h, int(n)))

@@ -214,6 +214,23 @@ class SubFramePool {
     bool quit_ = false;
 };
 
+// One frame in flight of rt_render_submit / rt_render_wait: a frame context, a stream and a host thread of its own (the
+// host side of a frame polls the level totals the kernels publish, so every frame in flight needs a thread).
+struct AsyncSlot {
+    FrameCtx ctx;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    enum { IDLE, QUEUED, DONE } state = IDLE;
+    bool quit = false;
+    rt_render_config cfg{};
+    float* d_out = nullptr;
+    int n_in_flight = 1;  // frames in flight on the GPU when this one was submitted (itself included)
+    rt_render_stats st{};
+    int rc = 0;
+    char err[512] = "";
+};
+
 constexpr uint64_t kDeviceBuildMinTriangles = 16384;
 constexpr uint32_t kTailMaxRays = 1u << 18;
 constexpr bool kClipDefault = true;  // RT_CLIP=0: every ray walks the whole line like the reference (same results)
@@ -325,6 +342,9 @@ struct rt_ads {
     FrameCtx frame[kMaxRenderStreams];
     int render_streams = 1;
     SubFramePool* pool = nullptr;
+    // rt_render_submit / rt_render_wait: whole frames in flight, one slot each (created on first use)
+    AsyncSlot* async_slots = nullptr;
+    int async_in_flight = 0;
     DevBuf<float> d_stage;
     DevBuf<uint8_t> d_io;  // staging for host-memory query calls
     SearchWork search;
@@ -668,6 +688,19 @@ void rt_ads_destroy(rt_ads* a) {
     if (!a) return;
     (void)hipSetDevice(a->device);
     delete a->pool;  // joins the sub-frame threads
+    if (a->async_slots) {
+        for (int k = 0; k < kMaxRenderStreams; ++k) {
+            AsyncSlot& s = a->async_slots[k];
+            {
+                std::lock_guard<std::mutex> lock(s.m);
+                s.quit = true;
+            }
+            s.cv.notify_all();
+            if (s.th.joinable()) s.th.join();  // (a frame still in flight is completed first)
+            s.ctx.release();
+        }
+        delete[] a->async_slots;
+    }
     a->d_nodes.release(); a->d_slots.release(); a->d_slot_geom.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_stage.release(); a->d_io.release();
     for (auto& x : a->frame) x.release();
@@ -1901,6 +1934,101 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
     if (a->collect_stats) {
         if (int rc = stats_end(a, stream)) return rc;
     }
+    a->q.search_calls += st.rays;
+    a->q.closest_rays += st.primary_rays + st.secondary_rays;
+    a->q.any_rays += st.shadow_rays;
+    a->q.search_seconds += ((double)st.ms_closest + (double)st.ms_shadow) * 1e-3;
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// The host thread of one frame slot: renders the frames submitted to it, one at a time.
+void async_slot_loop(rt_ads* a, AsyncSlot* s) {
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lock(s->m);
+            s->cv.wait(lock, [&] { return s->quit || s->state == AsyncSlot::QUEUED; });
+            if (s->state != AsyncSlot::QUEUED) return;  // quit with nothing queued
+        }
+        rt_render_stats st{};
+        // (n_sub = 1: with whole frames in flight a small level need not fill the chip on its own, and the fused tail
+        // is the cheapest way through it -- measured with 2..8 frames in flight)
+        const int rc = render_bands(a, s->ctx, &s->cfg, s->d_out, s->ctx.own_stream, 1, st);
+        {
+            std::lock_guard<std::mutex> lock(s->m);
+            s->st = st;
+            s->rc = rc;
+            if (rc) snprintf(s->err, sizeof s->err, "%s", g_err);
+            s->state = AsyncSlot::DONE;
+        }
+        s->cv.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_submit(rt_ads* a, const rt_render_config* c, float* out_rgb_device, void* stream_, int* ticket) {
+    if (!a || !c || !out_rgb_device || !ticket) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    if (a->collect_stats) return fail(RT_ERR_UNSUPPORTED, "the instrumented pass keeps one set of totals: use rt_render while rt_ads_collect_search_stats is on");
+    if (int rc = use_device(a)) return rc;
+    {
+        FrameParams F;
+        uint32_t n0 = 0;
+        if (int rc = frame_params(a, c, F, n0)) return rc;  // argument checks
+    }
+    if (!a->async_slots) a->async_slots = new AsyncSlot[kMaxRenderStreams];
+    int k = 0;
+    for (; k < kMaxRenderStreams; ++k) {
+        std::lock_guard<std::mutex> lock(a->async_slots[k].m);
+        if (a->async_slots[k].state == AsyncSlot::IDLE) break;
+    }
+    if (k == kMaxRenderStreams) return fail(RT_ERR_CAPACITY, "%d frames are in flight already: rt_render_wait one first", kMaxRenderStreams);
+    AsyncSlot& s = a->async_slots[k];
+    FrameCtx& x = s.ctx;
+    if (!x.own_stream) HIP_TRY(hipStreamCreateWithFlags(&x.own_stream, hipStreamNonBlocking));
+    if (!x.ev_fork) HIP_TRY(hipEventCreateWithFlags(&x.ev_fork, hipEventDisableTiming));
+    // the frame starts behind what the caller's stream holds now
+    HIP_TRY(hipEventRecord(x.ev_fork, (hipStream_t)stream_));
+    HIP_TRY(hipStreamWaitEvent(x.own_stream, x.ev_fork, 0));
+    if (!s.th.joinable()) s.th = std::thread(async_slot_loop, a, &s);
+    {
+        std::lock_guard<std::mutex> lock(s.m);
+        s.cfg = *c;
+        s.d_out = out_rgb_device;
+        s.n_in_flight = ++a->async_in_flight;
+        s.rc = 0;
+        s.state = AsyncSlot::QUEUED;
+    }
+    s.cv.notify_all();
+    *ticket = k;
+    return RT_OK;
+}
+
+int rt_render_wait(rt_ads* a, int ticket, rt_render_stats* stats) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->async_slots || ticket < 0 || ticket >= kMaxRenderStreams) return fail(RT_ERR_INVALID, "no such frame in flight (ticket %d)", ticket);
+    AsyncSlot& s = a->async_slots[ticket];
+    rt_render_stats st{};
+    int rc = 0;
+    {
+        std::unique_lock<std::mutex> lock(s.m);
+        if (s.state == AsyncSlot::IDLE) return fail(RT_ERR_INVALID, "no such frame in flight (ticket %d)", ticket);
+        s.cv.wait(lock, [&] { return s.state == AsyncSlot::DONE; });
+        st = s.st;
+        rc = s.rc;
+        if (rc) snprintf(g_err, sizeof g_err, "%s", s.err);
+        s.state = AsyncSlot::IDLE;
+    }
+    --a->async_in_flight;
+    if (rc) return rc;
     a->q.search_calls += st.rays;
     a->q.closest_rays += st.primary_rays + st.secondary_rays;
     a->q.any_rays += st.shadow_rays;

@@ -224,3 +224,72 @@ def test_fused_tail_and_sub_frames_leave_the_frame_unchanged(rt, monkeypatch):
         assert (st.launches_tail > 0) == (tail != 0), (tail, streams)
         if tail == 1 << 30 and streams == 1:
             assert st.launches_closest == 1  # level 0 only: everything below ran in the fused launch
+
+
+def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
+    """rt_render_submit / rt_render_wait: frames in flight are the frames rt_render gives, bit for bit, with the same ray
+    counts -- several frames of one configuration, different configurations side by side, the bands of one frame as
+    separate frames in flight into one buffer, on a small tree (wave-together forms, branching recursion) and on a big one
+    (per-lane form, fused tail).  The ninth frame in flight is refused, so is a ticket that is not in flight."""
+    from test_gpu_parity import synthetic_scene
+    from test_zz_no_alloc import _Hip
+    hip = _Hip()  # device frame buffers through the HIP runtime the library is linked to
+
+    def dev_frame(kw):
+        return hip.alloc(kw["height"] * kw["width"] * 12, fill=0)
+
+    def host(ptr, kw):
+        return hip.download(ptr, np.float32, kw["height"] * kw["width"] * 3).reshape(kw["height"], kw["width"], 3)
+
+    cases = []
+    sc = scenes["sphere"]
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    g.Build(sc.pos)
+    g.set_shading(sc.norm, sc.matid, sc.materials)
+    cases.append((g, dict(fov=0.6, width=200, height=120, spp=2, spt=5, render_type="blinn_phong", shading="smooth", **CAMERAS["sphere"]),
+                  dict(fov=0.5, width=96, height=64, spt=2, render_type="diffusion", shading="flat", **CAMERAS["sphere"])))
+    s = synthetic_scene(6)
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
+    g.Build(s.pos)
+    g.set_shading(None, s.matid, s.materials)
+    cases.append((g, dict(fov=0.6, width=640, height=360, spt=1, render_type="phong", shading="flat", aspect_mode=1, **CAMERAS["original"]),
+                  dict(fov=0.4, width=128, height=200, spt=2, render_type="distance", shading="flat", **CAMERAS["original"])))
+    counts = lambda st: (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays, st.levels)
+    for g, kw_a, kw_b in cases:
+        cfg_a, cfg_b = rt.make_render_config(**kw_a), rt.make_render_config(**kw_b)
+        ref_a, st_a = g.render(cfg_a)
+        ref_b, st_b = g.render(cfg_b)
+        q0 = g.query_stats()["search_calls"]
+        # six frames in flight, the two configurations alternating
+        kws = [kw_a if i % 2 == 0 else kw_b for i in range(6)]
+        bufs = [dev_frame(kw) for kw in kws]
+        tickets = [g.render_submit(cfg_a if i % 2 == 0 else cfg_b, bufs[i]) for i in range(6)]
+        assert sorted(tickets) == list(range(6))
+        for i in (3, 0, 5, 1, 4, 2):  # retired in another order than submitted
+            st = g.render_wait(tickets[i])
+            ref, st_ref = (ref_a, st_a) if i % 2 == 0 else (ref_b, st_b)
+            assert np.array_equal(bits(host(bufs[i], kws[i])), bits(ref)), i
+            assert counts(st) == counts(st_ref), i
+        assert g.query_stats()["search_calls"] == q0 + 3 * (st_a.rays + st_b.rays)
+        # the bands of one frame as eight frames in flight into one buffer; a ninth is refused
+        out = dev_frame(kw_a)
+        tickets = [g.render_submit(rt.make_render_config(band_rank=r, band_world=8, **kw_a), out) for r in range(8)]
+        with pytest.raises(RuntimeError, match="in flight already"):
+            g.render_submit(cfg_b, bufs[1])
+        rays = sum(g.render_wait(t).rays for t in tickets)
+        assert np.array_equal(bits(host(out, kw_a)), bits(ref_a)) and rays == st_a.rays
+        with pytest.raises(RuntimeError, match="no such frame in flight"):
+            g.render_wait(tickets[0])
+        with pytest.raises(RuntimeError, match="no such frame in flight"):
+            g.render_wait(11)
+        # the blocking call between frames in flight, and the instrumented pass refused for frames in flight
+        t = g.render_submit(cfg_a, bufs[0])
+        again, _ = g.render(cfg_b)
+        g.render_wait(t)
+        assert np.array_equal(bits(again), bits(ref_b)) and np.array_equal(bits(host(bufs[0], kw_a)), bits(ref_a))
+        g.collect_search_stats(True)
+        with pytest.raises(RuntimeError, match="instrumented pass"):
+            g.render_submit(cfg_a, bufs[0])
+        g.collect_search_stats(False)
+        g.close()
+        hip.free(out, *bufs)
