@@ -271,18 +271,19 @@ class FrameLoop:
     depth > 0: that many frames are in flight on the GPU (rt_render_submit / rt_render_wait); a frame is handed to the
     gather when it is retired.  depth = 0: one blocking rt_render call per frame."""
 
-    def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True, depth=0):
+    def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True, depth=0, device="cuda"):
         from raytracer_amd import distributed as rd
         self.ads, self.torch, self.dist = ads, torch, dist
+        self.on_gpu = str(device).startswith("cuda")  # ("cpu": the loop's bookkeeping under test, with gloo and a stand-in renderer)
         self.H, self.W = wl["height"], wl["width"]
         self.cfg = rt.make_render_config(band_rank=rank, band_world=world, **render_kwargs(wl))
         self.depth = depth if overlap or dist is None else 0
         nbuf = 2 if self.depth == 0 else self.depth + 2
-        self.frames = [rd.alloc_frame(self.H, self.W, world, "cuda") for _ in range(nbuf)]
-        self.stream = torch.cuda.current_stream().cuda_stream
-        self.gathers = [rd.BandGather(self.H, self.W, rank, world, "cuda", dist) for _ in range(nbuf)]
+        self.frames = [rd.alloc_frame(self.H, self.W, world, device) for _ in range(nbuf)]
+        self.stream = torch.cuda.current_stream().cuda_stream if self.on_gpu else None
+        self.gathers = [rd.BandGather(self.H, self.W, rank, world, device, dist) for _ in range(nbuf)]
         self.overlap = dist is not None and overlap
-        self.worker = rd.GatherThread(self.frames, self.gathers) if self.overlap and use_thread else None
+        self.worker = rd.GatherThread(self.frames, self.gathers, device=device) if self.overlap and use_thread else None
         self.n = 0
         self.in_flight = []  # (ticket, buffer) of the frames submitted and not yet retired, oldest first
 
@@ -326,10 +327,12 @@ class FrameLoop:
             self.worker.wait()
         for g_ in self.gathers:
             g_.finish()
-        self.torch.cuda.synchronize()
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
         if self.dist is not None:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
 
     def timed(self, steps, acc=None):
         """Seconds for `steps` frames between two fences (barrier + device synchronisation on both sides)."""

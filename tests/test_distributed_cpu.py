@@ -140,6 +140,87 @@ def test_gather_thread(world, tmp_path):
         assert np.array_equal(got[k], want), k
 
 
+class _StandInRenderer:
+    """What bench.FrameLoop needs of the renderer: frame number f, row r -> every float of the row is 1000 f + r, written
+    into this rank's rows when the frame is waited for (a frame in flight is not complete before)."""
+
+    def __init__(self, rank, world):
+        self.rows = rd.rows_of_rank(H, rank, world)
+        self.loop = None
+        self.submitted = 0
+        self.pending = {}
+        self.order = []  # (frame number, buffer index) in submission order
+
+    def _buffer(self, ptr):
+        return next(i for i, f in enumerate(self.loop.frames) if f.data_ptr() == ptr)
+
+    def _fill(self, k, number):
+        for r in self.rows:
+            self.loop.frames[k][r] = float(1000 * number + r)
+
+    def render(self, cfg, out_ptr=None, stream=None):
+        k = self._buffer(out_ptr)
+        self.order.append((self.submitted, k))
+        self._fill(k, self.submitted)
+        self.submitted += 1
+        return None, None
+
+    def render_submit(self, cfg, out_ptr, stream=None):
+        k = self._buffer(out_ptr)
+        ticket = min(set(range(8)) - set(self.pending))
+        self.pending[ticket] = (self.submitted, k)
+        self.order.append((self.submitted, k))
+        self.loop.frames[k].fill_(-1.0)  # the buffer of a frame in flight holds nothing usable
+        self.submitted += 1
+        return ticket
+
+    def render_wait(self, ticket):
+        number, k = self.pending.pop(ticket)
+        self._fill(k, number)
+        return None
+
+
+def _frame_loop_worker(rank, world, port, out_path, depth):
+    """bench.FrameLoop itself (ring of buffers, frames in flight, gathers on the worker thread) over gloo."""
+    import bench
+    import raytracer_amd as rt
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = dict(bench.WORKLOADS["cornell_original_blinn_spt4_256"], width=W, height=H)
+        ads = _StandInRenderer(rank, world)
+        loop = bench.FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=depth, device="cpu")
+        ads.loop = loop
+        assert len(loop.frames) == (2 if depth == 0 else depth + 2)
+        loop.warm(1)
+        loop.timed(7)
+        assert not loop.in_flight and not ads.pending
+        if rank == 0:
+            # after the fence every buffer of the ring holds the complete frame that was rendered into it last
+            last = {}
+            for number, k in ads.order:
+                last[k] = number
+            np.save(out_path, np.stack([np.concatenate([[float(last[k])], loop.frames[k][:H, 0, 0].numpy()]) for k in sorted(last)]))
+        loop.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth", [(2, 0), (2, 3), (3, 4)])
+def test_bench_frame_loop_with_frames_in_flight(world, depth, tmp_path):
+    out = str(tmp_path / "loop.npy")
+    mp.spawn(_frame_loop_worker, args=(world, _free_port(), out, depth), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape[0] == (2 if depth == 0 else depth + 2)
+    numbers = sorted(int(row[0]) for row in got)
+    total = 7 + max(1, 2 * depth)
+    assert numbers == list(range(total - len(numbers), total))  # the newest frames, one per buffer
+    for row in got:
+        assert np.array_equal(row[1:], 1000 * row[0] + np.arange(H, dtype=np.float32)), int(row[0])
+
+
 def test_band_bookkeeping():
     for h in (1, 7, 8, 9, 1080, 2160):
         for world in (1, 2, 3, 8):
