@@ -42,7 +42,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Frames in flight run on streams of the library's own; the HIP runtime maps streams onto this many hardware queues
 # (its default is 4, which serialises pairs of them).  Read when the runtime starts, so it is set before torch is loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (the GPU boxes export the default, so it is overridden, not defaulted; RT_BENCH_HW_QUEUES=0 leaves it alone)
+if os.environ.get("RT_BENCH_HW_QUEUES", "8") != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
 
 CAM_ORIGINAL = dict(cam_pos=[278.0, 273.0, -1000.0], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=2000.0)
 CAM_SPHERE = dict(cam_pos=[0.0, 1.0, 4.42], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, -1.0], max_distance=6.0)
@@ -461,7 +463,7 @@ def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=Non
             fl = FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=FRAMES_IN_FLIGHT)
             fl.warm()
             facc = new_acc()
-            n_fl = max(frames, 2 * FRAMES_IN_FLIGHT)
+            n_fl = max(frames, 2 * FRAMES_IN_FLIGHT, min(40, int(100.0 / res["ms_per_frame"])))  # (filling and draining the pipeline are inside)
             fl_s = fl.timed(n_fl, facc)
             fl.close()
             res["in_flight"] = {"depth": FRAMES_IN_FLIGHT, "frames": n_fl, "ms_per_frame": fl_s / n_fl * 1e3, "Mrays_per_s": facc["rays"] / fl_s / 1e6}

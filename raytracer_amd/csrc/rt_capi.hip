@@ -125,6 +125,10 @@ constexpr int kMaxTimed = 64;
 // Everything one frame in flight owns: the level buffers of the recursion, the counters, the mailboxes through which
 // the kernels tell the host the level sizes, the timing events.  A handle has one per concurrent sub-frame.
 constexpr int kMaxRenderStreams = 8;
+#ifndef RT_MAX_FRAMES_IN_FLIGHT
+#define RT_MAX_FRAMES_IN_FLIGHT 8
+#endif
+constexpr int kMaxFramesInFlight = RT_MAX_FRAMES_IN_FLIGHT;  // slots of rt_render_submit
 struct FrameCtx {
     std::vector<Level> levels;
     DevBuf<uint32_t> d_counters;  // one CNT_WORDS block per level
@@ -689,7 +693,7 @@ void rt_ads_destroy(rt_ads* a) {
     (void)hipSetDevice(a->device);
     delete a->pool;  // joins the sub-frame threads
     if (a->async_slots) {
-        for (int k = 0; k < kMaxRenderStreams; ++k) {
+        for (int k = 0; k < kMaxFramesInFlight; ++k) {
             AsyncSlot& s = a->async_slots[k];
             {
                 std::lock_guard<std::mutex> lock(s.m);
@@ -1984,13 +1988,13 @@ int rt_render_submit(rt_ads* a, const rt_render_config* c, float* out_rgb_device
         uint32_t n0 = 0;
         if (int rc = frame_params(a, c, F, n0)) return rc;  // argument checks
     }
-    if (!a->async_slots) a->async_slots = new AsyncSlot[kMaxRenderStreams];
+    if (!a->async_slots) a->async_slots = new AsyncSlot[kMaxFramesInFlight];
     int k = 0;
-    for (; k < kMaxRenderStreams; ++k) {
+    for (; k < kMaxFramesInFlight; ++k) {
         std::lock_guard<std::mutex> lock(a->async_slots[k].m);
         if (a->async_slots[k].state == AsyncSlot::IDLE) break;
     }
-    if (k == kMaxRenderStreams) return fail(RT_ERR_CAPACITY, "%d frames are in flight already: rt_render_wait one first", kMaxRenderStreams);
+    if (k == kMaxFramesInFlight) return fail(RT_ERR_CAPACITY, "%d frames are in flight already: rt_render_wait one first", kMaxFramesInFlight);
     AsyncSlot& s = a->async_slots[k];
     FrameCtx& x = s.ctx;
     if (!x.own_stream) HIP_TRY(hipStreamCreateWithFlags(&x.own_stream, hipStreamNonBlocking));
@@ -2014,7 +2018,7 @@ int rt_render_submit(rt_ads* a, const rt_render_config* c, float* out_rgb_device
 
 int rt_render_wait(rt_ads* a, int ticket, rt_render_stats* stats) {
     if (!a) return fail(RT_ERR_INVALID, "null argument");
-    if (!a->async_slots || ticket < 0 || ticket >= kMaxRenderStreams) return fail(RT_ERR_INVALID, "no such frame in flight (ticket %d)", ticket);
+    if (!a->async_slots || ticket < 0 || ticket >= kMaxFramesInFlight) return fail(RT_ERR_INVALID, "no such frame in flight (ticket %d)", ticket);
     AsyncSlot& s = a->async_slots[ticket];
     rt_render_stats st{};
     int rc = 0;

@@ -8,10 +8,10 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (first: it sets the number of hardware queues, which is read when HIP starts)
 import torch  # noqa: E402
 import raytracer_amd as rt  # noqa: E402
 from raytracer_amd.scene import Scene  # noqa: E402
-import bench  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT_WORKLOAD
 wl = bench.WORKLOADS[name]

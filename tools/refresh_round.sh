@@ -17,3 +17,9 @@ echo band done
 # the 1.31 M-triangle frame with 3 concurrent sub-frames per call (rt_ads_set_render_streams)
 RT_RENDER_STREAMS=3 timeout -k 10 200 python3 tools/band_time.py synthetic_ico8_phong_4k > gpurun_out/band_times_streams3.txt 2>/dev/null
 echo band streams done
+# one rank's share with 4 frames in flight (rt_render_submit / rt_render_wait) beside the blocking call (depth 0)
+: > gpurun_out/inflight_times.txt
+for w in cornell_original_blinn_spt16_1080p synthetic_ico8_phong_4k cornell_sphere_blinn_smooth_spp4_1080p; do
+  INFLIGHT_WORLDS=1,2,4,8 INFLIGHT_DEPTHS=0,4 timeout -k 10 200 python3 tools/inflight_time.py $w >> gpurun_out/inflight_times.txt 2>/dev/null
+done
+echo in-flight done
