@@ -240,6 +240,16 @@ int rt_render(rt_ads* ads, const rt_render_config* cfg, float* out_rgb, int mem,
  * (Renderer::RenderScene, renderer.cc:37-52, is one sequential loop). */
 int rt_ads_set_render_streams(rt_ads* ads, int n);
 
+/* Per-light forms of the wave-together any-hit walks (no reference counterpart; the visibility bits are the ones
+ * Renderer::is_shadowed, renderer.cc:288-313, computes).  With back-face culling on, a triangle whose front side holds a
+ * whole light -- every vertex of the light triangle at least a rounding margin in front of its plane -- can never be an
+ * accepted occluder of a shadow ray that ends on that light (collision_detection.h:31-35 rejects it from behind; from the
+ * front the ray ends before it reaches the plane, renderer.cc:302), so rt_render's any-hit passes towards that light
+ * walk lists without it.  Built by rt_scene_set_shading for trees in the small-tree or clustered form and at most 64
+ * lights; RT_LIGHT_CULL=0 in the environment at rt_ads_create switches it off.  Reports the lights that have such lists,
+ * the (light, triangle) pairs of the scene and how many of them are left out. */
+int rt_ads_light_forms(const rt_ads* ads, uint32_t* lights_with_forms, uint64_t* pairs, uint64_t* pairs_left_out);
+
 /* Frames in flight.  rt_render returns when its frame is complete, so a caller that renders a sequence of frames (or,
  * with several GPUs, its bands of each) leaves the GPU to one frame at a time -- and a short frame is a chain of
  * launches that each last as long as their slowest wavefront.  rt_render_submit queues a frame and returns at once with a

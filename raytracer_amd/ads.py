@@ -213,6 +213,13 @@ class GpuOctree(Ads):
         _capi.check(_capi.lib().rt_ads_tree_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def light_forms(self):
+        """(lights whose any-hit passes walk lists of their own, (light, triangle) pairs of the scene, pairs left out of
+        those lists because the triangle can never occlude that light with back-face culling on); zeros = not in use."""
+        a, b, c = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _capi.check(_capi.lib().rt_ads_light_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
     def tree_stats(self):
         st = _capi.TreeStats()
         _capi.check(_capi.lib().rt_ads_tree_stats(self._h, C.byref(st)))

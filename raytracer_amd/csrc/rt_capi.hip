@@ -336,6 +336,16 @@ struct rt_ads {
     // every triangle has |e1| * |e2| far below the range limit of the refined reciprocal: shadow rays (unit directions)
     // may use the any-hit triangle test that never needs the full division (any_hit_exec)
     bool fast_tri = false;
+    // Per-light forms (make_light_forms): host copies of the small-tree triangle list and of the clustered form, kept
+    // from Build so that rt_scene_set_shading can derive each light's lists once it knows the lights
+    std::vector<LeafTri> h_flat_tris, h_cl_tris;
+    std::vector<NodeRec> h_cl_nodes;
+    bool light_cull = true;  // RT_LIGHT_CULL=0 at creation: every light's any-hit passes walk the full lists
+    DevBuf<LightForm> d_light_forms;
+    DevBuf<LeafTri> d_light_flat, d_light_cl_tris;
+    DevBuf<NodeRec> d_light_cl_nodes;
+    bool light_forms_ready = false;
+    uint64_t light_pairs = 0, light_pairs_culled = 0;  // (light, triangle) pairs of the scene / those left out
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
     DevBuf<MatDev> d_mats;
@@ -674,6 +684,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
         return fail(RT_ERR_INVALID, "unknown builder %u", cfg->builder);
     }
     a->builder = (int)cfg->builder;
+    if (const char* e = getenv("RT_LIGHT_CULL")) a->light_cull = !(e[0] == '0');
     if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
     // the fixed scratch of rt_ads_search_noalloc: its address on this device, looked up with the device current
     {
@@ -708,6 +719,7 @@ void rt_ads_destroy(rt_ads* a) {
     a->d_nodes.release(); a->d_slots.release(); a->d_slot_geom.release(); a->d_tri_geom.release(); a->d_tri_shade.release(); a->d_vnorm.release();
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_stage.release(); a->d_io.release();
     for (auto& x : a->frame) x.release();
+    a->d_light_forms.release(); a->d_light_flat.release(); a->d_light_cl_tris.release(); a->d_light_cl_nodes.release();
     a->search.release();
     a->d_qstats.release();
     if (a->h_qstats) (void)hipHostFree(a->h_qstats);
@@ -743,6 +755,7 @@ int host_build(rt_ads* a) {
     a->n_slots = flat.slots.size();
     a->n_tree_nodes = host.nodes.size();
     a->n_flat_tris = flat.flat_tris.size();
+    a->h_flat_tris = flat.flat_tris;
     a->build_seconds = host.build_seconds;
     a->shape = tree_shape(host);
     if (int rc = check_tree_limits(a)) return rc;
@@ -780,6 +793,8 @@ int host_build(rt_ads* a) {
 int make_cluster_form(rt_ads* a) {
     a->n_clusters = 0;
     a->cl_root_info1 = 0;
+    a->h_cl_nodes.clear();
+    a->h_cl_tris.clear();
     if (a->empty || a->n_rec == 0 || !(a->root_info[1] & kChildInternal)) return RT_OK;
     if (a->traversal != 1 && a->n_slots >= kWaveFormMaxSlots) return RT_OK;  // its any-hit rays use the per-lane / pool forms
     if (a->n_slots > kClusterSlotMask) return RT_OK;
@@ -796,6 +811,140 @@ int make_cluster_form(rt_ads* a) {
     HIP_TRY(hipMemcpy(a->d_cl_tris.p, cf.tris.data(), cf.tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
     a->n_clusters = cf.n_clusters;
     a->cl_root_info1 = cf.root_info1;
+    a->h_cl_nodes = std::move(cf.nodes);
+    a->h_cl_tris = std::move(cf.tris);
+    return RT_OK;
+}
+
+// Per-light forms of the small-tree triangle list and of the clustered form.
+//
+// With back faces culled (collision_detection.h:31-35: d = dot(e1, cross(s, e2)) < epsilon is a miss) a triangle j can
+// occlude a shadow ray only where the ray runs AGAINST its geometric normal N = e1 x e2, i.e. from the side N points to
+// towards the other side.  A shadow ray ends at a point of the light (renderer.cc:302 keeps t < dist only).  If the whole
+// light triangle lies on the side N points to, at least m away from j's plane, a ray that ends on the light and runs
+// against N has not reached the plane yet when it ends: its plane crossing lies beyond the light by at least m along the
+// ray, whatever its origin.  The reference's own arithmetic cannot turn that into an accepted hit as long as m exceeds
+// what rounding can move the computed t: t = dot(e2, w) / d with relative errors of a few 2^-24 in each factor moves t by
+// less than 4 * 2^-24 * (k * (|q| + dist) + dist), k = |e1||e2| / |N| (1 for a right angle at a), also for grazing rays,
+// where numerator and d shrink together; a ray that runs parallel to the plane keeps its distance h >= m from it and
+// gets t = h |N| / (rounding noise of d) > 31 D.  With every point of the scene inside a box of diagonal D,
+//     m_j = 64 * 2^-24 * (2 k_j + 1) * D
+// is sixteen times that bound (0.011 for the Cornell box: the light quad hangs 0.1 below the ceiling).  Such a triangle
+// is left out of light l's lists: the candidates it would have contributed are never accepted, so every visibility bit
+// is the one the reference computes.  Nothing changes for two-sided tests (cull off), for caller-supplied segments
+// (rt_ads_trace_any) or for closest-hit rays: those walk the full lists.
+constexpr uint32_t kMaxLightForms = 64;
+int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
+    a->light_forms_ready = false;
+    a->light_pairs = a->light_pairs_culled = 0;
+    const size_t nl = light_tri.size();
+    const bool have_flat = !a->h_flat_tris.empty(), have_cl = !a->h_cl_nodes.empty();
+    if (nl == 0 || nl > kMaxLightForms || (!have_flat && !have_cl)) return RT_OK;
+    const uint64_t n = a->n_tri;
+    // the box of all vertices and its diagonal
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint64_t i = 0; i < n * 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double x = a->positions[i * 3 + k];
+            lo[k] = std::min(lo[k], x);
+            hi[k] = std::max(hi[k], x);
+        }
+    double D = 0.0;
+    for (int k = 0; k < 3; ++k) D += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+    D = std::sqrt(D);
+    if (!std::isfinite(D)) return RT_OK;
+    // culled[l * n + j]: triangle j cannot occlude light l
+    std::vector<uint8_t> culled(nl * n, 0);
+    for (uint64_t j = 0; j < n; ++j) {
+        const float* p = a->positions.data() + j * 9;
+        // the edges as the kernels hold them (rounded to float), everything after that in double
+        double e1[3], e2[3], N[3];
+        for (int k = 0; k < 3; ++k) {
+            e1[k] = (double)(float)(p[3 + k] - p[k]);
+            e2[k] = (double)(float)(p[6 + k] - p[k]);
+        }
+        N[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        N[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        N[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const double nn = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        if (!(nn > 0.0) || !std::isfinite(nn)) continue;  // a degenerate triangle stays in every list
+        const double kappa = l1 * l2 / nn;
+        const double m = 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
+        if (!std::isfinite(m)) continue;
+        for (size_t l = 0; l < nl; ++l) {
+            const float* q = a->positions.data() + (size_t)light_tri[l] * 9;
+            bool in_front = true;
+            for (int v = 0; v < 3 && in_front; ++v) {
+                double side = 0.0;
+                for (int k = 0; k < 3; ++k) side += N[k] * ((double)q[v * 3 + k] - (double)p[k]);
+                in_front = side / nn >= m;
+            }
+            if (in_front) culled[l * n + j] = 1;
+        }
+    }
+    for (uint8_t c : culled) a->light_pairs_culled += c;
+    a->light_pairs = (uint64_t)nl * n;
+    std::vector<LightForm> forms(nl);
+    for (auto& f : forms) f = LightForm{nullptr, nullptr, nullptr, 0u, 0u};
+    LeafTri zero;
+    memset(&zero, 0, sizeof zero);
+    if (have_flat) {  // per light: the triangles in their order, padded to whole blocks with records that list no leaf
+        std::vector<LeafTri> all;
+        std::vector<size_t> first(nl);
+        std::vector<uint32_t> count(nl);
+        for (size_t l = 0; l < nl; ++l) {
+            first[l] = all.size();
+            for (const LeafTri& t : a->h_flat_tris)
+                if (!culled[l * n + t.tri]) all.push_back(t);
+            do all.push_back(zero); while ((all.size() - first[l]) % kTriChunk != 0);  // (at least one record: a count of 0 means "no small-tree form")
+            count[l] = (uint32_t)(all.size() - first[l]);
+        }
+        for (int k = 0; k < kTriChunk; ++k) all.push_back(zero);  // the pass reads whole blocks
+        HIP_TRY(a->d_light_flat.reserve(all.size()));
+        HIP_TRY(hipMemcpy(a->d_light_flat.p, all.data(), all.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+        for (size_t l = 0; l < nl; ++l) {
+            forms[l].flat_tris = a->d_light_flat.p + first[l];
+            forms[l].n_flat_tris = count[l];
+        }
+    }
+    if (have_cl) {  // per light: every cluster's list without the culled triangles, and node records that point at them
+        const size_t n_rec = a->h_cl_nodes.size();
+        std::vector<NodeRec> nodes;
+        std::vector<LeafTri> tris;
+        std::vector<size_t> tri_first(nl);
+        nodes.reserve(nl * n_rec);
+        for (size_t l = 0; l < nl; ++l) {
+            tri_first[l] = tris.size();
+            for (size_t r = 0; r < n_rec; ++r) {
+                NodeRec rec = a->h_cl_nodes[r];
+                const uint32_t begin = rec.pad[0], cnt = rec.pad[1];
+                if (cnt != 0) {
+                    const size_t at = tris.size();
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const LeafTri& t = a->h_cl_tris[begin + k];
+                        if (t.pad0 != 0 && !culled[l * n + t.tri]) tris.push_back(t);  // (pad0 == 0: the old list's padding)
+                    }
+                    while ((tris.size() - at) % kTriChunk != 0) tris.push_back(zero);
+                    rec.pad[0] = (uint32_t)(at - tri_first[l]);
+                    rec.pad[1] = (uint32_t)(tris.size() - at);
+                }
+                nodes.push_back(rec);
+            }
+        }
+        for (int k = 0; k < kTriChunk; ++k) tris.push_back(zero);
+        HIP_TRY(a->d_light_cl_nodes.reserve(nodes.size()));
+        HIP_TRY(a->d_light_cl_tris.reserve(tris.size()));
+        HIP_TRY(hipMemcpy(a->d_light_cl_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(a->d_light_cl_tris.p, tris.data(), tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+        for (size_t l = 0; l < nl; ++l) {
+            forms[l].cl_nodes = a->d_light_cl_nodes.p + l * n_rec;
+            forms[l].cl_tris = a->d_light_cl_tris.p + tri_first[l];
+        }
+    }
+    HIP_TRY(a->d_light_forms.reserve(nl));
+    HIP_TRY(hipMemcpy(a->d_light_forms.p, forms.data(), nl * sizeof(LightForm), hipMemcpyHostToDevice));
+    a->light_forms_ready = true;
     return RT_OK;
 }
 
@@ -819,6 +968,7 @@ int device_build(rt_ads* a) {
     a->root_info[0] = a->root_info[1] = 0;
     a->max_stack = 0;
     a->n_rec = a->n_slots = a->n_tree_nodes = a->n_flat_tris = 0;
+    a->h_flat_tris.clear();
     a->shape = TreeShape();
     a->build_seconds = 0.0;
     if (n == 0) return RT_OK;  // octree.cc:24-27
@@ -1063,6 +1213,16 @@ int rt_ads_tree_forms(const rt_ads* a, uint64_t* small_tree_triangles, uint32_t*
     if (small_tree_triangles) *small_tree_triangles = a->use_flat ? a->n_flat_tris : 0;
     if (clusters) *clusters = a->use_clusters ? a->n_clusters : 0u;
     if (fast_any_hit) *fast_any_hit = a->fast_tri ? 1 : 0;
+    return RT_OK;
+}
+
+int rt_ads_light_forms(const rt_ads* a, uint32_t* lights_with_forms, uint64_t* pairs, uint64_t* pairs_left_out) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    const bool on = a->light_cull && a->light_forms_ready;
+    if (lights_with_forms) *lights_with_forms = on ? a->n_lights : 0u;
+    if (pairs) *pairs = on ? a->light_pairs : 0u;
+    if (pairs_left_out) *pairs_left_out = on ? a->light_pairs_culled : 0u;
     return RT_OK;
 }
 
@@ -1491,6 +1651,7 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         HIP_TRY(hipMemcpy(a->d_vnorm.p, normals, n * 9 * sizeof(float), hipMemcpyHostToDevice));
     }
     a->n_lights = (uint32_t)light_tri.size();
+    if (int rc = make_light_forms(a, light_tri)) return rc;
     a->shading_set = true;
     return RT_OK;
 }
@@ -1551,6 +1712,7 @@ SceneDev scene_dev(const rt_ads* a) {
     S.mats = a->d_mats.p;
     S.lights = a->d_lights.p;
     S.n_lights = a->n_lights;
+    S.light_forms = (a->light_cull && a->light_forms_ready) ? a->d_light_forms.p : nullptr;
     return S;
 }
 

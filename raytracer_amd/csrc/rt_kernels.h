@@ -134,6 +134,18 @@ struct alignas(16) LightDev {  // one emissive triangle (obj_loader.cc:188-191)
 };
 static_assert(sizeof(LightDev) == 64, "");
 
+// What the any-hit passes towards ONE light walk instead of the scene's full small-tree / clustered arrays: the same
+// arrays without the triangles that can never occlude that light when back faces are culled (make_light_forms in
+// rt_capi.hip states the condition).  Null pointers: that form does not exist for the tree.
+struct alignas(16) LightForm {
+    const LeafTri* flat_tris;  // small-tree form: the light's triangle list (whole 4-record blocks, at least one)
+    const NodeRec* cl_nodes;   // clustered form: the node records with the light's list positions ...
+    const LeafTri* cl_tris;    // ... and its cluster lists
+    uint32_t n_flat_tris;
+    uint32_t pad;
+};
+static_assert(sizeof(LightForm) == 32, "");
+
 struct alignas(16) RayRec {  // one node of the recursion tree waiting to be traced
     float o[3], d[3];
     uint32_t parent;   // index of the parent node in the previous level
@@ -161,6 +173,7 @@ struct SceneDev {
     const MatDev* mats;
     const LightDev* lights;
     uint32_t n_lights;
+    const LightForm* light_forms;  // per light, or nullptr (culling off at creation, too many lights, no such forms)
 };
 
 struct FrameParams {
@@ -585,7 +598,25 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
         HitState h;
-        trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
+        if constexpr (CULL && (MODE == MODE_WAVE || MODE == MODE_CLUSTER)) {
+            // one light per pass: the wave walks that light's own lists (wave-uniform record, scalar loads)
+            DevOctree T = S.tree;
+            if (S.light_forms != nullptr) {
+                // (the wave-together forms are launched with one light per pass: group <= samples per light)
+                const LightForm& lf = S.light_forms[(uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift))];
+                if (MODE == MODE_WAVE && T.n_flat_tris != 0 && lf.flat_tris != nullptr) {
+                    T.flat_tris = lf.flat_tris;
+                    T.n_flat_tris = lf.n_flat_tris;
+                }
+                if (MODE == MODE_CLUSTER && lf.cl_nodes != nullptr) {
+                    T.cl_nodes = lf.cl_nodes;
+                    T.cl_tris = lf.cl_tris;
+                }
+            }
+            trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
+        } else {
+            trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
+        }
         const lanemask unshadowed = on_mask & ~h.found;
         const uint32_t word = smp >> 5;
         if (lit && writer && word < words)

@@ -197,6 +197,7 @@ def test_fused_tail_and_sub_frames_leave_the_frame_unchanged(rt, monkeypatch):
     of the image, a ray count or the depth reached: level by level, fused from the first level that qualifies, fused from
     level 1 on, and 3 / 8 sub-frames with and without the fused launch all give the same frame."""
     from test_gpu_parity import synthetic_scene
+    monkeypatch.delenv("RT_CLIP", raising=False)  # (the fused launch belongs to the clipped per-lane walks, the default)
     s = synthetic_scene(6)  # 81,954 triangles: per-lane form
     kw = dict(fov=0.6, width=960, height=540, spt=1, render_type="phong", shading="flat", aspect_mode=1, **CAMERAS["original"])
     cfg = rt.make_render_config(**kw)
@@ -293,3 +294,59 @@ def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
         g.collect_search_stats(False)
         g.close()
         hip.free(out, *bufs)
+
+
+@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered"])
+def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, case):
+    """With back-face culling on, the any-hit passes towards a light walk lists without the triangles that hold the whole
+    light in front of them (they can never be accepted occluders of a ray that ends on it).  The frames must be the ones
+    of the full lists bit for bit -- same image, same ray counts -- and the oracle's within the shading tolerance, on the
+    two shipped scenes and on random triangle soups with emissive triangles at arbitrary angles (small-tree and clustered
+    form); and the lists must really leave something out."""
+    if case in ("original", "sphere"):
+        sc = scenes[case]
+        pos, nrm, matid, mats = sc.pos, (sc.norm if sc.has_normals else None), sc.matid, sc.materials
+        cam = CAMERAS[case]
+        kw = dict(fov=0.6, width=160, height=120, spt=7, render_type="blinn_phong", shading="smooth" if nrm is not None else "flat", max_depth=3, **cam)
+        mb, md = 16, 10
+    else:
+        n_tri, mb, md = (150, 64, 1) if case == "soup_small_tree" else (1500, 8, 5)
+        rs = np.random.RandomState(11 if case == "soup_small_tree" else 12)
+        centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+        size = np.exp(rs.uniform(np.log(0.05), np.log(3.0), (n_tri, 1, 1)))
+        pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+        mats = scenes["sphere"].materials
+        emissive = [m for m in range(mats.shape[0]) if np.any(mats[m, 12:15] != 0)]
+        plain = [m for m in range(mats.shape[0]) if m not in emissive]
+        matid = np.asarray(plain, np.int32)[rs.randint(0, len(plain), n_tri)]
+        matid[[3, n_tri // 2, n_tri - 5]] = emissive[0]  # three lights wherever the soup put them
+        nrm = None
+        kw = dict(fov=0.9, width=120, height=96, spt=5, render_type="phong", shading="flat", max_depth=2, cam_pos=[0.5, 0.3, -14.0],
+                  cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=40.0)
+    cfg = rt.make_render_config(**kw)
+    frames = {}
+    for cull_lists in ("1", "0"):
+        monkeypatch.setenv("RT_LIGHT_CULL", cull_lists)
+        g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+        g.Build(pos)
+        g.set_shading(nrm, matid, mats)
+        lights, pairs, left_out = g.light_forms()
+        small, clusters, _ = g.tree_forms()
+        if case in ("original", "soup_small_tree"):
+            assert small > 0  # the small-tree form serves the shadow rays
+        else:
+            assert small == 0 and clusters > 0  # the clustered form does
+        if cull_lists == "1":
+            assert lights >= 2 and 0 < left_out < pairs, (lights, pairs, left_out)
+        else:
+            assert (lights, pairs, left_out) == (0, 0, 0)
+        img, st = g.render(cfg)
+        frames[cull_lists] = (img, (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays, st.levels))
+        g.close()
+    monkeypatch.delenv("RT_LIGHT_CULL")
+    assert np.array_equal(bits(frames["1"][0]), bits(frames["0"][0]))
+    assert frames["1"][1] == frames["0"][1] and frames["1"][1][3] > 10000
+    osc = orc.Scene.from_arrays(pos, nrm, matid, mats)
+    ref, _, _, ost = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, **kw), want_hits=False)
+    assert np.abs(frames["1"][0] - ref).max() <= 1.0 / 255.0
+    assert frames["1"][1][0] == ost.search_calls
