@@ -344,7 +344,9 @@ struct rt_ads {
     DevBuf<LightForm> d_light_forms;
     DevBuf<LeafTri> d_light_flat, d_light_cl_tris;
     DevBuf<NodeRec> d_light_cl_nodes;
-    bool light_forms_ready = false;
+    DevBuf<NodeRec> d_light_lane_nodes;   // per-lane form: per light a copy of the node records ...
+    DevBuf<float> d_light_lane_geom;      // ... and the geometry of the slots its leaves keep
+    bool light_forms_ready = false, light_forms_lane = false;
     uint64_t light_pairs = 0, light_pairs_culled = 0;  // (light, triangle) pairs of the scene / those left out
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
@@ -720,6 +722,7 @@ void rt_ads_destroy(rt_ads* a) {
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_stage.release(); a->d_io.release();
     for (auto& x : a->frame) x.release();
     a->d_light_forms.release(); a->d_light_flat.release(); a->d_light_cl_tris.release(); a->d_light_cl_nodes.release();
+    a->d_light_lane_nodes.release(); a->d_light_lane_geom.release();
     a->search.release();
     a->d_qstats.release();
     if (a->h_qstats) (void)hipHostFree(a->h_qstats);
@@ -833,13 +836,17 @@ int make_cluster_form(rt_ads* a) {
 // is left out of light l's lists: the candidates it would have contributed are never accepted, so every visibility bit
 // is the one the reference computes.  Nothing changes for two-sided tests (cull off), for caller-supplied segments
 // (rt_ads_trace_any) or for closest-hit rays: those walk the full lists.
-constexpr uint32_t kMaxLightForms = 64;
+constexpr uint32_t kMaxLightForms = 64, kMaxLaneLightForms = 8;
 int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
-    a->light_forms_ready = false;
+    a->light_forms_ready = a->light_forms_lane = false;
     a->light_pairs = a->light_pairs_culled = 0;
     const size_t nl = light_tri.size();
     const bool have_flat = !a->h_flat_tris.empty(), have_cl = !a->h_cl_nodes.empty();
-    if (nl == 0 || nl > kMaxLightForms || (!have_flat && !have_cl)) return RT_OK;
+    // a tree whose any-hit rays are walked per lane: per-light node records and slot geometry (a few lights only: every
+    // light costs a copy of the node records and up to a copy of the slot geometry)
+    const bool have_lane = !a->empty && (a->root_info[1] & kChildInternal) && a->n_rec != 0 && nl <= kMaxLaneLightForms &&
+                           (a->traversal == 2 || (a->traversal == 0 && a->n_slots >= kWaveFormMaxSlots && !(a->use_flat && a->n_flat_tris != 0)));
+    if (nl == 0 || nl > kMaxLightForms || (!have_flat && !have_cl && !have_lane)) return RT_OK;
     const uint64_t n = a->n_tri;
     // the box of all vertices and its diagonal
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -886,7 +893,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     for (uint8_t c : culled) a->light_pairs_culled += c;
     a->light_pairs = (uint64_t)nl * n;
     std::vector<LightForm> forms(nl);
-    for (auto& f : forms) f = LightForm{nullptr, nullptr, nullptr, 0u, 0u};
+    for (auto& f : forms) memset(&f, 0, sizeof f);
     LeafTri zero;
     memset(&zero, 0, sizeof zero);
     if (have_flat) {  // per light: the triangles in their order, padded to whole blocks with records that list no leaf
@@ -941,6 +948,68 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
             forms[l].cl_nodes = a->d_light_cl_nodes.p + l * n_rec;
             forms[l].cl_tris = a->d_light_cl_tris.p + tri_first[l];
         }
+    }
+    if (have_lane) {
+        const size_t n_rec = a->n_rec, n_slots = a->n_slots;
+        std::vector<NodeRec> nodes(n_rec);
+        std::vector<LeafTri> slots(n_slots);
+        HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
+        std::vector<NodeRec> all_nodes(nl * n_rec);
+        std::vector<float> geom;
+        std::vector<size_t> geom_first(nl);
+        std::vector<uint32_t> root1(nl), pref(n_slots + 1);
+        for (size_t l = 0; l < nl; ++l) {
+            const uint8_t* cl = culled.data() + l * n;
+            geom_first[l] = geom.size();
+            // the slots that stay, in their order; pref[s] = how many of the slots before s stay
+            uint32_t kept = 0;
+            for (size_t sidx = 0; sidx < n_slots; ++sidx) {
+                pref[sidx] = kept;
+                const LeafTri& t = slots[sidx];
+                if (cl[t.tri]) continue;
+                const float g9[9] = {t.ax, t.ay, t.az, t.e1x, t.e1y, t.e1z, t.e2x, t.e2y, t.e2z};
+                geom.insert(geom.end(), g9, g9 + 9);
+                ++kept;
+            }
+            pref[n_slots] = kept;
+            for (int k = 0; k < 9 * kTriChunk; ++k) geom.push_back(0.0f);  // (a lane without a pair reads record 0 of its list)
+            // records bottom-up (children follow their parents in the array): leaf ranges renumbered, leaves and
+            // subtrees without a triangle become empty octants
+            NodeRec* out = all_nodes.data() + l * n_rec;
+            for (size_t r = n_rec; r-- > 0;) {
+                NodeRec rec = nodes[r];
+                uint32_t nonempty = 0;
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t i0 = rec.info[c][0], i1 = rec.info[c][1];
+                    if (i1 == 0) continue;
+                    if (i1 & kChildInternal) {
+                        if (i0 <= r || i0 >= n_rec) return fail(RT_ERR_BUILD, "internal: node records are not in breadth-first order");
+                        if (out[i0].nonempty == 0) rec.info[c][0] = rec.info[c][1] = 0;
+                    } else {
+                        if ((uint64_t)i0 + i1 > n_slots) return fail(RT_ERR_BUILD, "internal: leaf range beyond the slot array");
+                        const uint32_t nb = pref[i0], nc = pref[i0 + i1] - pref[i0];
+                        rec.info[c][0] = nc ? nb : 0u;
+                        rec.info[c][1] = nc;
+                    }
+                    if (rec.info[c][1] != 0) nonempty |= 1u << c;
+                }
+                rec.nonempty = nonempty;
+                node_ordered_nonempty(nonempty, &rec.pad[1]);
+                out[r] = rec;
+            }
+            root1[l] = out[a->root_info[0]].nonempty != 0 ? a->root_info[1] : 0u;  // (0: nothing can occlude this light)
+        }
+        HIP_TRY(a->d_light_lane_nodes.reserve(all_nodes.size()));
+        HIP_TRY(a->d_light_lane_geom.reserve(geom.size()));
+        HIP_TRY(hipMemcpy(a->d_light_lane_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(a->d_light_lane_geom.p, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+        for (size_t l = 0; l < nl; ++l) {
+            forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
+            forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
+            forms[l].lane_root_info1 = root1[l];
+        }
+        a->light_forms_lane = true;
     }
     HIP_TRY(a->d_light_forms.reserve(nl));
     HIP_TRY(hipMemcpy(a->d_light_forms.p, forms.data(), nl * sizeof(LightForm), hipMemcpyHostToDevice));
@@ -1906,7 +1975,9 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 const int mode_a = traversal_mode(a, false, true, (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle);
                 gshift = 0;
                 const bool wave_a = mode_a == MODE_WAVE || mode_a == MODE_CLUSTER;
-                while (!wave_a && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
+                // (with per-light forms of the tree a per-lane pass, too, serves one light at a time)
+                const bool light_passes = wave_a || (mode_a == MODE_LANE && F.cull && a->light_cull && a->light_forms_lane);
+                while (!light_passes && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 const dim3 block_a(wave_a ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);

@@ -142,9 +142,14 @@ struct alignas(16) LightForm {
     const NodeRec* cl_nodes;   // clustered form: the node records with the light's list positions ...
     const LeafTri* cl_tris;    // ... and its cluster lists
     uint32_t n_flat_tris;
-    uint32_t pad;
+    // per-lane form (big trees): the node records with the light's leaf ranges -- octants and subtrees left without a
+    // triangle are marked empty -- and the geometry of the slots that remain (DevOctree::nodes / slot_geom / root_info)
+    uint32_t lane_root_info1;
+    const NodeRec* lane_nodes;
+    const float* lane_slot_geom;
+    uint64_t pad[2];
 };
-static_assert(sizeof(LightForm) == 32, "");
+static_assert(sizeof(LightForm) == 64, "");
 
 struct alignas(16) RayRec {  // one node of the recursion tree waiting to be traced
     float o[3], d[3];
@@ -598,12 +603,20 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
         HitState h;
-        if constexpr (CULL && (MODE == MODE_WAVE || MODE == MODE_CLUSTER)) {
+        if constexpr (CULL && (MODE == MODE_WAVE || MODE == MODE_CLUSTER || MODE == MODE_LANE)) {
             // one light per pass: the wave walks that light's own lists (wave-uniform record, scalar loads)
             DevOctree T = S.tree;
-            if (S.light_forms != nullptr) {
-                // (the wave-together forms are launched with one light per pass: group <= samples per light)
-                const LightForm& lf = S.light_forms[(uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift))];
+            // (the wave-together forms are always launched with one light per pass, group <= samples per light; the
+            // per-lane form is when the scene has per-light forms)
+            if (S.light_forms != nullptr && gshift <= pshift) {
+                // (read through the constant address space: scalar loads, the pointers stay in scalar registers)
+                const RT_CONST LightForm& lf =
+                    *(const RT_CONST LightForm*)(uintptr_t)(S.light_forms + (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)));
+                if (MODE == MODE_LANE && lf.lane_nodes != nullptr) {
+                    T.nodes = lf.lane_nodes;
+                    T.slot_geom = lf.lane_slot_geom;
+                    T.root_info1 = lf.lane_root_info1;
+                }
                 if (MODE == MODE_WAVE && T.n_flat_tris != 0 && lf.flat_tris != nullptr) {
                     T.flat_tris = lf.flat_tris;
                     T.n_flat_tris = lf.n_flat_tris;

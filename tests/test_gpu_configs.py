@@ -296,19 +296,28 @@ def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
         hip.free(out, *bufs)
 
 
-@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered"])
+@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered", "big_tree_per_lane"])
 def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, case):
     """With back-face culling on, the any-hit passes towards a light walk lists without the triangles that hold the whole
     light in front of them (they can never be accepted occluders of a ray that ends on it).  The frames must be the ones
     of the full lists bit for bit -- same image, same ray counts -- and the oracle's within the shading tolerance, on the
-    two shipped scenes and on random triangle soups with emissive triangles at arbitrary angles (small-tree and clustered
-    form); and the lists must really leave something out."""
+    two shipped scenes, on random triangle soups with emissive triangles at arbitrary angles (small-tree and clustered
+    form) and on a big tree, whose per-lane walks get per-light node records and slot geometry (octants and subtrees
+    left without a triangle become empty); and the lists must really leave something out."""
+    rows = None
     if case in ("original", "sphere"):
         sc = scenes[case]
         pos, nrm, matid, mats = sc.pos, (sc.norm if sc.has_normals else None), sc.matid, sc.materials
         cam = CAMERAS[case]
         kw = dict(fov=0.6, width=160, height=120, spt=7, render_type="blinn_phong", shading="smooth" if nrm is not None else "flat", max_depth=3, **cam)
         mb, md = 16, 10
+    elif case == "big_tree_per_lane":
+        from test_gpu_parity import synthetic_scene
+        sy = synthetic_scene(6)  # 81,954 triangles
+        pos, nrm, matid, mats = sy.pos, None, sy.matid, sy.materials
+        kw = dict(fov=0.6, width=480, height=270, spt=3, render_type="phong", shading="flat", aspect_mode=1, max_depth=4, **CAMERAS["original"])
+        mb, md = 16, 10
+        rows = (120, 150)  # (the oracle's share: rows through the sphere)
     else:
         n_tri, mb, md = (150, 64, 1) if case == "soup_small_tree" else (1500, 8, 5)
         rs = np.random.RandomState(11 if case == "soup_small_tree" else 12)
@@ -334,6 +343,8 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
         small, clusters, _ = g.tree_forms()
         if case in ("original", "soup_small_tree"):
             assert small > 0  # the small-tree form serves the shadow rays
+        elif case == "big_tree_per_lane":
+            assert small == 0 and clusters == 0  # the per-lane form does
         else:
             assert small == 0 and clusters > 0  # the clustered form does
         if cull_lists == "1":
@@ -347,6 +358,11 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
     assert np.array_equal(bits(frames["1"][0]), bits(frames["0"][0]))
     assert frames["1"][1] == frames["0"][1] and frames["1"][1][3] > 10000
     osc = orc.Scene.from_arrays(pos, nrm, matid, mats)
-    ref, _, _, ost = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, **kw), want_hits=False)
-    assert np.abs(frames["1"][0] - ref).max() <= 1.0 / 255.0
-    assert frames["1"][1][0] == ost.search_calls
+    okw = dict(kw, aspect_mode=orc.ASPECT_TRUE) if kw.get("aspect_mode") else kw
+    if rows is None:
+        ref, _, _, ost = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, **okw), want_hits=False)
+        assert np.abs(frames["1"][0] - ref).max() <= 1.0 / 255.0
+        assert frames["1"][1][0] == ost.search_calls
+    else:
+        ref, _, _, _ = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=rows, **okw), want_hits=False)
+        assert np.abs(frames["1"][0][rows[0]:rows[1]] - ref[rows[0]:rows[1]]).max() <= 1.0 / 255.0
