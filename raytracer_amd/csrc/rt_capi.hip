@@ -255,7 +255,12 @@ constexpr uint64_t kWaveFormMaxSlots = 32768;  // trees with fewer leaf slots ar
     } while (0)
 
 template <class... Args>
-void launch_shadow(bool cull, int mode, bool fast_tri, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+void launch_shadow(bool cull, int mode, bool fast_tri, bool side, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    if (mode == MODE_LANE && side && cull) {  // (per-light trees exist for culled tests only)
+        if (fast_tri) hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1, true, true>), grid, block, lds, stream, args...);
+        else hipLaunchKernelGGL((k_shadow<true, MODE_LANE, 1, false, true>), grid, block, lds, stream, args...);
+        return;
+    }
 #define RT_SHADOW_CASE(MODE, WAVES)                                                                                          \
     if (mode == MODE) {                                                                                                      \
         if (fast_tri && cull) hipLaunchKernelGGL((k_shadow<true, MODE, WAVES, true>), grid, block, lds, stream, args...);     \
@@ -347,6 +352,9 @@ struct rt_ads {
     DevBuf<NodeRec> d_light_lane_nodes;   // per-lane form: per light a copy of the node records ...
     DevBuf<float> d_light_lane_geom;      // ... and the geometry of the slots its leaves keep
     bool light_forms_ready = false, light_forms_lane = false;
+    // per-lane any-hit passes with per-light trees: launches of more rays than this serve one light per pass, smaller
+    // ones keep all lights of a hit side by side (RT_LANE_SIDE_MAX_RAYS)
+    uint64_t lane_side_max_rays = 1ull << 22;
     uint64_t light_pairs = 0, light_pairs_culled = 0;  // (light, triangle) pairs of the scene / those left out
     DevBuf<TriShade> d_tri_shade;
     DevBuf<float> d_vnorm;
@@ -687,6 +695,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
     }
     a->builder = (int)cfg->builder;
     if (const char* e = getenv("RT_LIGHT_CULL")) a->light_cull = !(e[0] == '0');
+    if (const char* e = getenv("RT_LANE_SIDE_MAX_RAYS")) a->lane_side_max_rays = (uint64_t)atoll(e);
     if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
     // the fixed scratch of rt_ads_search_noalloc: its address on this device, looked up with the device current
     {
@@ -845,6 +854,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     // a tree whose any-hit rays are walked per lane: per-light node records and slot geometry (a few lights only: every
     // light costs a copy of the node records and up to a copy of the slot geometry)
     const bool have_lane = !a->empty && (a->root_info[1] & kChildInternal) && a->n_rec != 0 && nl <= kMaxLaneLightForms &&
+                           (uint64_t)a->n_rec * nl < (1ull << 24) && (uint64_t)(a->n_slots + kTriChunk) * nl < (1ull << 31) &&
                            (a->traversal == 2 || (a->traversal == 0 && a->n_slots >= kWaveFormMaxSlots && !(a->use_flat && a->n_flat_tris != 0)));
     if (nl == 0 || nl > kMaxLightForms || (!have_flat && !have_cl && !have_lane)) return RT_OK;
     const uint64_t n = a->n_tri;
@@ -1008,6 +1018,8 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
             forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
             forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
             forms[l].lane_root_info1 = root1[l];
+            forms[l].lane_rec_base = (uint32_t)(l * n_rec);
+            forms[l].lane_slot_base = (uint32_t)(geom_first[l] / 9);
         }
         a->light_forms_lane = true;
     }
@@ -1976,13 +1988,16 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 gshift = 0;
                 const bool wave_a = mode_a == MODE_WAVE || mode_a == MODE_CLUSTER;
                 // (with per-light forms of the tree a per-lane pass, too, serves one light at a time)
-                const bool light_passes = wave_a || (mode_a == MODE_LANE && F.cull && a->light_cull && a->light_forms_lane);
+                // ... unless the launch is small: then the lights of a hit stay side by side (a shorter chain of walks per
+                // wave) and every lane walks its own light's tree
+                const bool light_trees = mode_a == MODE_LANE && F.cull && a->light_cull && a->light_forms_lane;
+                const bool light_passes = wave_a || (light_trees && (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle > a->lane_side_max_rays);
                 while (!light_passes && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave
                 const dim3 block_a(wave_a ? 256 : 64);
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
-                launch_shadow(F.cull != 0, mode_a, a->fast_tri, grid_a, block_a, lane_lds(a, mode_a, block_a.x, false), stream, S, F, L, lv.rays.p, cap,
+                launch_shadow(F.cull != 0, mode_a, a->fast_tri, light_trees && gshift > pshift, grid_a, block_a, lane_lds(a, mode_a, block_a.x, false), stream, S, F, L, lv.rays.p, cap,
                               lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words, pshift, gshift, cnt, launch_opts(a, sparse_a));
                 HIP_TRY(hipGetLastError());
                 st.launches_shadow++;

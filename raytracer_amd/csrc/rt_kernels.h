@@ -89,13 +89,16 @@ __device__ __forceinline__ uint64_t ray_index(uint64_t g, uint32_t sparse, bool&
     return ((g >> 6) << (6u - sparse)) + lane;
 }
 // FAST: any-hit rays with unit-length directions in a scene within the bound of any_hit_exec.
-template <bool ANY, bool CULL, int MODE, bool FAST = false>
-__device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, uint32_t opts, bool valid, f3 o, f3 d, float t_limit, HitState& h) {
+// BASES (per-lane any-hit walks only): see traverse_lane_any.
+template <bool ANY, bool CULL, int MODE, bool FAST = false, bool BASES = false>
+__device__ __forceinline__ void trace(const DevOctree& T, TraverseLds<MODE>& lds, uint32_t opts, bool valid, f3 o, f3 d, float t_limit, HitState& h,
+                                      uint32_t rec_base = 0, uint32_t slot_base = 0) {
+    static_assert(!BASES || (ANY && MODE == MODE_LANE), "");
     const bool clip = opts_clip(opts);
     if constexpr (MODE == MODE_LANE) {
         const uint32_t levels = opts_levels(opts);
         const LaneStack stk = lane_stack(rt_dyn_lds + (threadIdx.x >> 6) * lane_stack_words(levels, !ANY), levels, !ANY);
-        traverse_lane<ANY, CULL, ANY && FAST>(T, stk, valid, o, d, t_limit, clip, h);
+        traverse_lane<ANY, CULL, ANY && FAST, BASES>(T, stk, valid, o, d, t_limit, clip, h, rec_base, slot_base);
     } else if constexpr (MODE == MODE_POOL) {
         traverse_pool<ANY, CULL, ANY && FAST>(T, lds.s, valid, o, d, t_limit, clip, h);
     } else if constexpr (MODE == MODE_CLUSTER) {
@@ -147,7 +150,10 @@ struct alignas(16) LightForm {
     uint32_t lane_root_info1;
     const NodeRec* lane_nodes;
     const float* lane_slot_geom;
-    uint64_t pad[2];
+    // the same copies seen from light 0's arrays (all lights' copies lie one after the other): what a lane adds to the
+    // record and slot indices of its light's copy when the lanes of a wave walk different lights' trees
+    uint32_t lane_rec_base, lane_slot_base;
+    uint64_t pad;
 };
 static_assert(sizeof(LightForm) == 64, "");
 
@@ -550,7 +556,9 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 // WAVES: waves per block.  The kernel has no block-level step, so the per-lane and pool forms run one-wave blocks:
 // a wave that finishes frees its slot at once instead of waiting for the slowest of four.
 // FAST: see trace<>.
-template <bool CULL, int MODE, int WAVES, bool FAST = false>
+// SIDE (per-lane form with per-light trees only): all lights of a hit side by side, every lane walking the tree of its
+// own light (two more vector registers: 6 instead of 7 waves per SIMD, so it is an instantiation of its own).
+template <bool CULL, int MODE, int WAVES, bool FAST = false, bool SIDE = false>
 __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow(SceneDev S, FrameParams F, uint32_t level, const RayRec* __restrict__ rays, uint32_t n,
                                                 const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,
                                                 const uint32_t* __restrict__ work, uint32_t* __restrict__ vis, uint32_t words,
@@ -626,7 +634,22 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
                     T.cl_tris = lf.cl_tris;
                 }
             }
-            trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
+            if constexpr (MODE == MODE_LANE && SIDE) {
+                // all lights of a hit side by side (gshift > pshift): every lane walks the tree of its own light
+                uint32_t rec_base = 0, slot_base = 0;
+                bool walk = on;
+                if (S.light_forms != nullptr && gshift > pshift && S.light_forms[0].lane_nodes != nullptr) {
+                    const LightForm& lf = S.light_forms[lit ? l : 0u];
+                    T.nodes = S.light_forms[0].lane_nodes;
+                    T.slot_geom = S.light_forms[0].lane_slot_geom;
+                    rec_base = lf.lane_rec_base;
+                    slot_base = lf.lane_slot_base;
+                    walk = on && lf.lane_root_info1 != 0u;
+                }
+                trace<true, CULL, MODE, FAST, true>(T, lds[threadIdx.x >> 6], opts, walk, P, d_l, dist, h, rec_base, slot_base);
+            } else {
+                trace<true, CULL, MODE, FAST>(T, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
+            }
         } else {
             trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
         }
@@ -945,7 +968,19 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
             const float dist = length(to_l);
             const f3 d_l = normalize(to_l);
             HitState hs;
-            trace<true, CULL, MODE_LANE, FAST>(S.tree, lds[0], opts, on, gP, d_l, dist, hs);
+            // every lane walks the tree of its own light where the scene has per-light trees (LightForm)
+            DevOctree T = S.tree;
+            uint32_t rec_base = 0, slot_base = 0;
+            bool walk = on;
+            if (CULL && S.light_forms != nullptr && S.light_forms[0].lane_nodes != nullptr) {
+                const LightForm& lf = S.light_forms[on ? l : 0u];
+                T.nodes = S.light_forms[0].lane_nodes;
+                T.slot_geom = S.light_forms[0].lane_slot_geom;
+                rec_base = lf.lane_rec_base;
+                slot_base = lf.lane_slot_base;
+                walk = on && lf.lane_root_info1 != 0u;  // (0: nothing can occlude that light)
+            }
+            trace<true, CULL, MODE_LANE, FAST, true>(T, lds[0], opts, walk, gP, d_l, dist, hs, rec_base, slot_base);
             const lanemask unshadowed = ballot64(on) & ~hs.found;
             vis_bits = (unshadowed >> lead) & group_mask;
         }

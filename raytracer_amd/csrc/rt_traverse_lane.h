@@ -222,10 +222,15 @@ __device__ __forceinline__ uint32_t lanes_below(lanemask m) {  // set bits of m 
 }
 
 // Any-hit walk of the rays with `valid` set; returns the lanes whose ray has an occluder.  t_limit: distance to the light.
-template <bool CULL, bool FAST>
-__device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, Span sp) {
+// BASES: the lanes walk different copies of the tree that lie in one pair of arrays (per-light trees, one light per
+// lane): rec_base / slot_base are added to every record index / leaf slot index a lane reads from its copy, and travel
+// with the ray when another lane takes over part of its walk.
+template <bool CULL, bool FAST, bool BASES = false>
+__device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, Span sp,
+                                                      uint32_t rec_base = 0, uint32_t slot_base = 0) {
     [[maybe_unused]] constexpr bool ANY = true;  // (the profiling macros index by it)
     const uint32_t tid = __lane_id();
+    if constexpr (!BASES) rec_base = slot_base = 0;
     f3 inv = reciprocal3(d, valid);  // collision_detection.h:76
     uint32_t flip = ray_flip(inv);
     uint32_t owner = tid;    // the home lane of the ray this lane works on
@@ -237,10 +242,10 @@ __device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const 
     uint32_t cur_rec = 0, cur_pending = 0;
     int sp_n = 0, sb = 0;  // the lane's stack entries are [sb, sp_n)
     if (!(T.root_info1 & kChildInternal)) {  // the root is a leaf: all triangles, no box test (octree.cc:56-63,186-191)
-        leaf_slot = T.root_info0;
+        leaf_slot = T.root_info0 + slot_base;
         leaf_left = active ? T.root_info1 : 0u;
     } else {
-        cur_rec = T.root_info0;
+        cur_rec = T.root_info0 + rec_base;
         cur_pending = active ? lane_node_pass<false>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, nullptr) : 0u;
     }
 #ifdef RT_LANE_PROFILE
@@ -278,9 +283,15 @@ __device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const 
                         const f3 t_inv = mk(__shfl(inv.x, (int)from, 64), __shfl(inv.y, (int)from, 64), __shfl(inv.z, (int)from, 64));
                         const uint32_t t_flip = __shfl(flip, (int)from, 64), t_owner = __shfl(owner, (int)from, 64);
                         const float t_tl = __shfl(t_limit, (int)from, 64), t_lo = __shfl(sp.lo, (int)from, 64), t_hi = __shfl(sp.hi, (int)from, 64);
+                        uint32_t t_rb = 0, t_sb = 0;
+                        if constexpr (BASES) {
+                            t_rb = __shfl(rec_base, (int)from, 64);
+                            t_sb = __shfl(slot_base, (int)from, 64);
+                        }
                         if (thief) {
                             o = t_o; d = t_d; inv = t_inv; flip = t_flip; owner = t_owner;
                             t_limit = t_tl; sp.lo = t_lo; sp.hi = t_hi;
+                            if constexpr (BASES) { rec_base = t_rb; slot_base = t_sb; }
                             cur_rec = e >> 8;
                             cur_pending = e & 0xffu;
                             active = true;
@@ -326,13 +337,13 @@ __device__ __forceinline__ lanemask traverse_lane_any(const DevOctree& T, const 
                             stk.e[sp_n * 64 + tid] = (cur_rec << 8) | cur_pending;
                             ++sp_n;
                         }
-                        cur_rec = info.x;
+                        cur_rec = info.x + rec_base;
                         cur_pending = lane_node_pass<false>(T.nodes, cur_rec, o, inv, flip, sp.lo, sp.hi, nullptr);
                     } else if (kTwo && leaf_left != 0) {
-                        leaf_slot2 = info.x;
+                        leaf_slot2 = info.x + slot_base;
                         leaf_left2 = info.y;
                     } else {
-                        leaf_slot = info.x;
+                        leaf_slot = info.x + slot_base;
                         leaf_left = info.y;
                     }
                 }
@@ -679,13 +690,13 @@ __device__ __forceinline__ void traverse_lane_closest(const DevOctree& T, const 
 // light; closest-hit rays walk front to back up to their best hit, and a ray whose best distance two distinct
 // triangles share is walked once more like the reference walks it (whole line, no pruning), which settles the tie by
 // the reference's own rule.
-template <bool ANY, bool CULL, bool FAST = false>
+template <bool ANY, bool CULL, bool FAST = false, bool BASES = false>
 __device__ __forceinline__ void traverse_lane(const DevOctree& T, const LaneStack& stk, bool valid, f3 o, f3 d, float t_limit, bool clip,
-                                              HitState& h) {
+                                              HitState& h, uint32_t rec_base = 0, uint32_t slot_base = 0) {
     hit_state_reset(h);
     if (T.root_info1 == 0 || ballot64(valid) == 0) return;  // empty tree / no rays
     if constexpr (ANY) {
-        h.found = traverse_lane_any<CULL, FAST>(T, stk, valid, o, d, t_limit, span_segment(o, t_limit, clip));
+        h.found = traverse_lane_any<CULL, FAST, BASES>(T, stk, valid, o, d, t_limit, span_segment(o, t_limit, clip), rec_base, slot_base);
     } else {
         bool todo = valid, pruned = clip;
 #pragma nounroll
