@@ -704,8 +704,10 @@ def main():
                 "achieved": sh.get("reference_equivalent_TFLOPs"), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": sh.get("frac_of_fp32_vector_peak"), "traffic": None,
                 "achieved_is": "reference-equivalent work: rays x (3 + 18 B + 52 T) flops of the reference algorithm per ray / kernel time; "
-                               "the kernel executes less (shared plane products, early exits, no duplicate triangles) and, bit-exact "
-                               "without FMA, can issue at most 78.6 T lane-ops/s",
+                               "the kernel executes less (shared plane products, early exits, no duplicate triangles, and with back-face culling "
+                               "the triangles that can never occlude the light are left out of its lists) and, bit-exact without FMA, can "
+                               "issue at most 78.6 T lane-ops/s -- so this fraction may exceed what the no-FMA issue peak would allow the "
+                               "reference's own operation count; valu_issue_frac is what the kernel really issues",
                 "frac_of_no_fma_issue_peak": sh.get("frac_of_no_fma_issue_peak"),
                 "algorithmic_flops_per_ray": work["any_hit"]["flops"] if work else None,
                 "launches": sh["launches"], "avg_launch_ms": sh["avg_launch_ms"],

@@ -768,6 +768,10 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
     } else if (valid) {  // renderer.cc:202-247
         const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
         f3 final_c = mk(0, 0, 0);
+        // the direction to the viewer (renderer.cc:257,277) depends on the hit alone: once per hit, not once per sample
+        // (the guarded division in normalize() tests its operands wave-wide, which keeps the compiler from moving it)
+        f3 d_v = mk(0, 0, 0);
+        if (wave_needs_pow) d_v = normalize(F.cam_pos - P);
         for (uint32_t l = 0; l < S.n_lights; ++l) {
             const LightDev L = S.lights[l];
             const f3 emission = mk(L.emission[0], L.emission[1], L.emission[2]);
@@ -797,7 +801,6 @@ __device__ __forceinline__ void shade_hit(const SceneDev& S, const FrameParams& 
                 const f3 I_d = (I_l * diffuse) * std_max(0.0f, dot(N, d_l));
                 float pw = 1.0f;  // the power of the specular term; irrelevant on lanes whose specular colour is zero
                 if (wave_needs_pow) {
-                    const f3 d_v = normalize(F.cam_pos - P);
                     if (F.render_type == 2) {  // renderer.cc:256-263
                         const f3 d_r = ((N * 2.0f) * dot(N, d_l)) - d_l;
                         pw = shade_pow(std_max(0.0f, dot(d_v, d_r)), m.shininess);

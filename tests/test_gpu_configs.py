@@ -296,7 +296,7 @@ def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
         hip.free(out, *bufs)
 
 
-@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered", "big_tree_per_lane"])
+@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered", "big_tree_per_lane", "soup_two_sided", "soup_many_lights"])
 def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, case):
     """With back-face culling on, the any-hit passes towards a light walk lists without the triangles that hold the whole
     light in front of them (they can never be accepted occluders of a ray that ends on it).  The frames must be the ones
@@ -319,8 +319,8 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
         mb, md = 16, 10
         rows = (120, 150)  # (the oracle's share: rows through the sphere)
     else:
-        n_tri, mb, md = (150, 64, 1) if case == "soup_small_tree" else (1500, 8, 5)
-        rs = np.random.RandomState(11 if case == "soup_small_tree" else 12)
+        n_tri, mb, md = (1500, 8, 5) if case == "soup_clustered" else (150, 64, 1)
+        rs = np.random.RandomState(12 if case == "soup_clustered" else 11)
         centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
         size = np.exp(rs.uniform(np.log(0.05), np.log(3.0), (n_tri, 1, 1)))
         pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
@@ -329,9 +329,15 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
         plain = [m for m in range(mats.shape[0]) if m not in emissive]
         matid = np.asarray(plain, np.int32)[rs.randint(0, len(plain), n_tri)]
         matid[[3, n_tri // 2, n_tri - 5]] = emissive[0]  # three lights wherever the soup put them
+        if case == "soup_many_lights":
+            matid[::2] = emissive[0]  # 75 lights: more than get lists of their own
         nrm = None
         kw = dict(fov=0.9, width=120, height=96, spt=5, render_type="phong", shading="flat", max_depth=2, cam_pos=[0.5, 0.3, -14.0],
                   cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=40.0)
+        if case == "soup_many_lights":
+            kw.update(width=48, height=40, spt=2)
+        if case == "soup_two_sided":
+            kw["cull"] = False  # the lists exist, the two-sided test must not use them
     cfg = rt.make_render_config(**kw)
     frames = {}
     for cull_lists in ("1", "0"):
@@ -341,13 +347,15 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
         g.set_shading(nrm, matid, mats)
         lights, pairs, left_out = g.light_forms()
         small, clusters, _ = g.tree_forms()
-        if case in ("original", "soup_small_tree"):
+        if case in ("original", "soup_small_tree", "soup_two_sided", "soup_many_lights"):
             assert small > 0  # the small-tree form serves the shadow rays
         elif case == "big_tree_per_lane":
             assert small == 0 and clusters == 0  # the per-lane form does
         else:
             assert small == 0 and clusters > 0  # the clustered form does
-        if cull_lists == "1":
+        if case == "soup_many_lights":
+            assert (lights, pairs, left_out) == (0, 0, 0)
+        elif cull_lists == "1":
             assert lights >= 2 and 0 < left_out < pairs, (lights, pairs, left_out)
         else:
             assert (lights, pairs, left_out) == (0, 0, 0)
