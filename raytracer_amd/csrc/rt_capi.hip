@@ -1227,6 +1227,7 @@ extern "C" {
 int rt_ads_build(rt_ads* a, const float* positions, uint64_t n) {
     if (!a || (!positions && n)) return fail(RT_ERR_INVALID, "null argument");
     if (n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "more than 2^31-1 triangles");
+    if (a->async_in_flight > 0) return fail(RT_ERR_INVALID, "%d frame(s) still in flight: rt_render_wait them before rebuilding", a->async_in_flight);
     if (int rc = use_device(a)) return rc;
     a->built = false;
     a->shading_set = false;
@@ -1657,6 +1658,7 @@ int rt_debug_triangle_tests(int device, const float* origins, const float* dirs,
 int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* material_ids, const float* materials, uint32_t n_mat) {
     if (!a || !material_ids || !materials) return fail(RT_ERR_INVALID, "null argument");
     if (!a->built) return fail(RT_ERR_NOT_BUILT, "rt_ads_build has not been called");
+    if (a->async_in_flight > 0) return fail(RT_ERR_INVALID, "%d frame(s) still in flight: rt_render_wait them first", a->async_in_flight);
     if (int rc = use_device(a)) return rc;
     const uint64_t n = a->n_tri;
     for (uint64_t i = 0; i < n; ++i)

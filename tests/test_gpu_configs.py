@@ -286,6 +286,8 @@ def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
         # the blocking call between frames in flight, and the instrumented pass refused for frames in flight
         t = g.render_submit(cfg_a, bufs[0])
         again, _ = g.render(cfg_b)
+        with pytest.raises(RuntimeError, match="still in flight"):
+            g.Build(np.zeros((1, 3, 3), np.float32))  # the scene may not change under a frame in flight
         g.render_wait(t)
         assert np.array_equal(bits(again), bits(ref_b)) and np.array_equal(bits(host(bufs[0], kw_a)), bits(ref_a))
         g.collect_search_stats(True)
