@@ -849,6 +849,7 @@ constexpr uint32_t kMaxLightForms = 64, kMaxLaneLightForms = 8;
 int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     a->light_forms_ready = a->light_forms_lane = false;
     a->light_pairs = a->light_pairs_culled = 0;
+    if (!a->light_cull) return RT_OK;
     const size_t nl = light_tri.size();
     const bool have_flat = !a->h_flat_tris.empty(), have_cl = !a->h_cl_nodes.empty();
     // a tree whose any-hit rays are walked per lane: per-light node records and slot geometry (a few lights only: every
