@@ -256,7 +256,10 @@ def memory_side(kernels, name, workload):
 def build_ads(rt, scene, wl, device=0):
     ads = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10}, device=device)
     ads.Build(scene.pos)
+    s0 = time.perf_counter()
     ads.set_shading(scene.norm, scene.matid, scene.materials)
+    # (materials, lights and the per-light lists / trees of the any-hit passes: host work, once per scene)
+    ads.shading_setup_s = time.perf_counter() - s0
     ads.set_render_streams(int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)))
     return ads
 
@@ -431,7 +434,7 @@ def run_other_workload(name, frames, rt, Scene, torch, rank=0, world=1, dist=Non
     ts = ads.tree_stats()
     res = {"Mrays_per_s": rays / elapsed / 1e6, "ms_per_frame": elapsed / frames * 1e3, "frames": frames,
            "rays_per_frame": rays // frames, "triangles": scene.n_triangles, "octree_nodes": ts["nodes"],
-           "octree_build_s": round(ts["build_seconds"], 4), "render_streams": int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)),
+           "octree_build_s": round(ts["build_seconds"], 4), "shading_setup_s": round(ads.shading_setup_s, 4), "render_streams": int(os.environ.get("RT_BENCH_STREAMS") or wl.get("streams", 1)),
            "n_gpus": world}
     if dist is not None:
         res["frames_in_flight"] = loop.depth
@@ -615,7 +618,7 @@ def main():
             "config": {"workload": args.workload, "width": W, "height": H, "samples_per_pixel": wl["spp"],
                        "samples_per_triangle": wl["spt"], "render_type": wl["render_type"], "shading": wl["shading"],
                        "octree": "max_triangles_per_BB=16,max_depth=10", "aspect_mode": "true" if aspect else "compat",
-                       "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3),
+                       "triangles": scene.n_triangles, "octree_nodes": tree_stats["nodes"], "octree_build_s": round(tree_stats["build_seconds"], 3), "shading_setup_s": round(ads.shading_setup_s, 4),
                        "rays_per_frame": rays // args.steps, "partition": f"8-row bands round-robin over {world} rank(s)",
                        "frames_in_flight": depth},
         }

@@ -873,7 +873,8 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     if (!std::isfinite(D)) return RT_OK;
     // culled[l * n + j]: triangle j cannot occlude light l
     std::vector<uint8_t> culled(nl * n, 0);
-    for (uint64_t j = 0; j < n; ++j) {
+    auto classify = [&](uint64_t j_begin, uint64_t j_end) {
+    for (uint64_t j = j_begin; j < j_end; ++j) {
         const float* p = a->positions.data() + j * 9;
         // the edges as the kernels hold them (rounded to float), everything after that in double
         double e1[3], e2[3], N[3];
@@ -900,6 +901,14 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
             }
             if (in_front) culled[l * n + j] = 1;
         }
+    }
+    };
+    {
+        const unsigned n_threads = n >= (1u << 16) ? 8u : 1u;
+        std::vector<std::thread> workers;
+        for (unsigned k = 1; k < n_threads; ++k) workers.emplace_back(classify, n * k / n_threads, n * (k + 1) / n_threads);
+        classify(0, n / n_threads);
+        for (auto& w : workers) w.join();
     }
     for (uint8_t c : culled) a->light_pairs_culled += c;
     a->light_pairs = (uint64_t)nl * n;
@@ -967,24 +976,29 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
         std::vector<NodeRec> all_nodes(nl * n_rec);
-        std::vector<float> geom;
+        std::vector<std::vector<float>> geom_of(nl);
         std::vector<size_t> geom_first(nl);
-        std::vector<uint32_t> root1(nl), pref(n_slots + 1);
-        for (size_t l = 0; l < nl; ++l) {
+        std::vector<uint32_t> root1(nl);
+        std::vector<int> bad(nl, 0);
+        // one host thread per light (at most kMaxLaneLightForms)
+        auto one_light = [&](size_t l) {
             const uint8_t* cl = culled.data() + l * n;
-            geom_first[l] = geom.size();
+            std::vector<float>& geom = geom_of[l];
+            std::vector<uint32_t> pref(n_slots + 1);
             // the slots that stay, in their order; pref[s] = how many of the slots before s stay
             uint32_t kept = 0;
             for (size_t sidx = 0; sidx < n_slots; ++sidx) {
                 pref[sidx] = kept;
-                const LeafTri& t = slots[sidx];
-                if (cl[t.tri]) continue;
-                const float g9[9] = {t.ax, t.ay, t.az, t.e1x, t.e1y, t.e1z, t.e2x, t.e2y, t.e2z};
-                geom.insert(geom.end(), g9, g9 + 9);
-                ++kept;
+                kept += cl[slots[sidx].tri] ? 0u : 1u;
             }
             pref[n_slots] = kept;
-            for (int k = 0; k < 9 * kTriChunk; ++k) geom.push_back(0.0f);  // (a lane without a pair reads record 0 of its list)
+            geom.resize(((size_t)kept + kTriChunk) * 9, 0.0f);  // (a lane without a pair reads record 0 of its list)
+            for (size_t sidx = 0; sidx < n_slots; ++sidx) {
+                const LeafTri& t = slots[sidx];
+                if (cl[t.tri]) continue;
+                float* g = geom.data() + (size_t)pref[sidx] * 9;
+                g[0] = t.ax; g[1] = t.ay; g[2] = t.az; g[3] = t.e1x; g[4] = t.e1y; g[5] = t.e1z; g[6] = t.e2x; g[7] = t.e2y; g[8] = t.e2z;
+            }
             // records bottom-up (children follow their parents in the array): leaf ranges renumbered, leaves and
             // subtrees without a triangle become empty octants
             NodeRec* out = all_nodes.data() + l * n_rec;
@@ -995,10 +1009,10 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
                     const uint32_t i0 = rec.info[c][0], i1 = rec.info[c][1];
                     if (i1 == 0) continue;
                     if (i1 & kChildInternal) {
-                        if (i0 <= r || i0 >= n_rec) return fail(RT_ERR_BUILD, "internal: node records are not in breadth-first order");
+                        if (i0 <= r || i0 >= n_rec) { bad[l] = 1; return; }  // (records not in breadth-first order)
                         if (out[i0].nonempty == 0) rec.info[c][0] = rec.info[c][1] = 0;
                     } else {
-                        if ((uint64_t)i0 + i1 > n_slots) return fail(RT_ERR_BUILD, "internal: leaf range beyond the slot array");
+                        if ((uint64_t)i0 + i1 > n_slots) { bad[l] = 2; return; }  // (leaf range beyond the slot array)
                         const uint32_t nb = pref[i0], nc = pref[i0 + i1] - pref[i0];
                         rec.info[c][0] = nc ? nb : 0u;
                         rec.info[c][1] = nc;
@@ -1010,11 +1024,25 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
                 out[r] = rec;
             }
             root1[l] = out[a->root_info[0]].nonempty != 0 ? a->root_info[1] : 0u;  // (0: nothing can occlude this light)
+        };
+        {
+            std::vector<std::thread> workers;
+            for (size_t l = 1; l < nl; ++l) workers.emplace_back(one_light, l);
+            one_light(0);
+            for (auto& w : workers) w.join();
+        }
+        for (size_t l = 0; l < nl; ++l)
+            if (bad[l]) return fail(RT_ERR_BUILD, "internal: the resident tree is not in the layout the per-light copies assume (%d)", bad[l]);
+        size_t geom_total = 0;
+        for (size_t l = 0; l < nl; ++l) {
+            geom_first[l] = geom_total;
+            geom_total += geom_of[l].size();
         }
         HIP_TRY(a->d_light_lane_nodes.reserve(all_nodes.size()));
-        HIP_TRY(a->d_light_lane_geom.reserve(geom.size()));
+        HIP_TRY(a->d_light_lane_geom.reserve(geom_total));
         HIP_TRY(hipMemcpy(a->d_light_lane_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(a->d_light_lane_geom.p, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+        for (size_t l = 0; l < nl; ++l)
+            HIP_TRY(hipMemcpy(a->d_light_lane_geom.p + geom_first[l], geom_of[l].data(), geom_of[l].size() * sizeof(float), hipMemcpyHostToDevice));
         for (size_t l = 0; l < nl; ++l) {
             forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
             forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
