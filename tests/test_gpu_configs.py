@@ -16,6 +16,7 @@ FORMS = {
     "plain": {"RT_DISABLE_SMALL_TREE": "1", "RT_DISABLE_CLUSTERS": "1"},
     "lane": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"},
     "pool": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"},
+    "full_lists": {"RT_LIGHT_CULL": "0"},                                   # no per-light lists: every any-hit pass walks everything
 }
 
 
@@ -31,7 +32,7 @@ def bits(a):
 
 def build(rt, sc, monkeypatch=None, form="auto", builder="auto"):
     if monkeypatch is not None:
-        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS"):
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_LIGHT_CULL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in FORMS[form].items():
             monkeypatch.setenv(k, v)
@@ -70,12 +71,13 @@ def test_original_spp64_spt32_full_size_properties(rt, orc, scenes, monkeypatch)
     sc = scenes["original"]
     kw = dict(fov=0.6, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong", shading="flat", **CAMERAS["original"])
     out = {}
-    for form in ("auto", "general"):
+    for form in ("auto", "general", "full_lists"):
         g = build(rt, sc, monkeypatch, form)
         img = np.zeros((2160, 3840, 3), np.float32)
         _, st = g.render(rt.make_render_config(band_rank=3, band_world=8, **kw), out=img)
         out[form] = (img, st.rays, st.shadow_rays)
-    assert np.array_equal(bits(out["auto"][0]), bits(out["general"][0])) and out["auto"][1:] == out["general"][1:]
+    for form in ("general", "full_lists"):
+        assert np.array_equal(bits(out["auto"][0]), bits(out[form][0])) and out["auto"][1:] == out[form][1:], form
     img = out["auto"][0]
     # band 3 = rows 24..31 belong to rank 3 of 8; rows 0..23 do not and must be untouched
     assert not img[:24].any() and img[24:32].any()
@@ -122,7 +124,7 @@ def test_sphere_spp4_spt32_full_size_properties(rt, orc, scenes, monkeypatch):
     ref, _, _, ost = orc.render(sc, orc.Octree(sc, 16, 10), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=(536, 544), **kw), want_hits=False)
     assert np.abs(full[536:544] - ref[536:544]).max() <= 1.0 / 255.0
     # the per-lane form and the plain wave-together walk on the same frame
-    for other in ("lane", "plain"):
+    for other in ("lane", "plain", "full_lists"):
         g2 = build(rt, sc, monkeypatch, other)
         img2, s2 = g2.render(cfg)
         assert np.array_equal(bits(img2), bits(full)) and s2.rays == st.rays, other
