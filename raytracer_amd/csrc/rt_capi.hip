@@ -871,6 +871,9 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     for (int k = 0; k < 3; ++k) D += (hi[k] - lo[k]) * (hi[k] - lo[k]);
     D = std::sqrt(D);
     if (!std::isfinite(D)) return RT_OK;
+    // (RT_LIGHT_CULL_MARGIN_SCALE: a test switch that shrinks the margin, to show where the rule starts to fail)
+    double margin_scale = 1.0;
+    if (const char* e = getenv("RT_LIGHT_CULL_MARGIN_SCALE")) margin_scale = atof(e);
     // culled[l * n + j]: triangle j cannot occlude light l
     std::vector<uint8_t> culled(nl * n, 0);
     auto classify = [&](uint64_t j_begin, uint64_t j_end) {
@@ -889,7 +892,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
         if (!(nn > 0.0) || !std::isfinite(nn)) continue;  // a degenerate triangle stays in every list
         const double kappa = l1 * l2 / nn;
-        const double m = 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
+        const double m = margin_scale * 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
         if (!std::isfinite(m)) continue;
         for (size_t l = 0; l < nl; ++l) {
             const float* q = a->positions.data() + (size_t)light_tri[l] * 9;

@@ -378,3 +378,62 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
     else:
         ref, _, _, _ = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=rows, **okw), want_hits=False)
         assert np.abs(frames["1"][0][rows[0]:rows[1]] - ref[rows[0]:rows[1]]).max() <= 1.0 / 255.0
+
+
+@pytest.mark.parametrize("factor", [1.02, 1.5, 4.0, 64.0])
+def test_per_light_lists_at_their_margin(rt, scenes, monkeypatch, factor):
+    """The worst case for the rule behind the per-light lists: a light that hovers only `factor` times the rule's rounding
+    margin in front of a large triangle pair (0.3 mm above a 20 m floor for factor 1.02), seen from surface points at
+    about the same height -- so the shadow rays run almost parallel to that floor, the regime where the triangle test's
+    determinant is rounding noise -- and from points well above and below it.  The floor is left out of the light's lists;
+    the frame must still be the one the full lists give, bit for bit.  (The test has teeth: run by hand with
+    RT_LIGHT_CULL_MARGIN_SCALE, which shrinks the margin in the library and here alike, it still passes at 1/256 of the
+    margin and fails at 1/4096.)"""
+    def quad(p0, p1, p2, p3):
+        return [[p0, p1, p2], [p0, p2, p3]]
+
+    diag = float(np.sqrt(20.0 ** 2 + 20.0 ** 2 + 2.0 ** 2))
+    import os
+    margin = 64.0 * 2.0 ** -24 * (2.0 * 1.0 + 1.0) * diag  # right triangles: |e1||e2| / |e1 x e2| = 1
+    margin *= float(os.environ.get("RT_LIGHT_CULL_MARGIN_SCALE", "1"))  # (a manual experiment: how far below the rule's margin does it hold?)
+    h = factor * margin
+    tris = []
+    tris += quad([-10, 0, -10], [-10, 0, 10], [10, 0, 10], [10, 0, -10])              # the floor, normal +y
+    tris += quad([-2, h, -2], [-2, h, 2], [2, h, 2], [2, h, -2])                        # the light, just above it, facing up
+    for sx in (-1.0, 1.0):                                                             # walls whose points see the light at grazing angles
+        tris += quad([9 * sx, -1, -10], [9 * sx, 1, -10], [9 * sx, 1, 10], [9 * sx, -1, 10])
+        tris += quad([-10, -1, 9 * sx], [10, -1, 9 * sx], [10, 1, 9 * sx], [-10, 1, 9 * sx])
+    pos = np.asarray(tris, np.float32)
+    mats = scenes["sphere"].materials
+    emissive = next(m for m in range(mats.shape[0]) if np.any(mats[m, 12:15] != 0))
+    plain = next(m for m in range(mats.shape[0]) if not np.any(mats[m, 12:15] != 0) and not np.any(mats[m, 6:12] != 0))
+    matid = np.full(len(pos), plain, np.int32)
+    matid[2:4] = emissive
+    frames = {}
+    for cull_lists in ("1", "0"):
+        monkeypatch.setenv("RT_LIGHT_CULL", cull_lists)
+        g = rt.GpuOctree({"max_triangles_per_BB": 4, "max_depth": 3})  # (a root leaf has no lists to thin out)
+        g.Build(pos)
+        g.set_shading(None, matid, mats)
+        if cull_lists == "1":
+            lights, pairs, left_out = g.light_forms()
+            assert lights == 2 and left_out >= 4  # the two floor triangles, for both light triangles
+        imgs = []
+        # the camera looks at a wall through a keyhole: hit points within a few margins of the light's height, then
+        # within a centimetre, then the whole wall
+        for fov, cam_y in ((2.0 * np.arctan(8.0 * h / 9.0), h), (2.0 * np.arctan(0.01 / 9.0), 0.5 * h), (0.2, 0.3), (0.2, -0.3)):
+            for cam_dir in ([1.0, 0.0, 0.0], [0.0, 0.0, -1.0]):
+                for two_sided in (False, True):
+                    cfg = rt.make_render_config(cam_pos=[0.0, float(cam_y), 0.0], cam_up=[0.0, 1.0, 0.0], cam_dir=cam_dir, fov=float(fov), width=96, height=96,
+                                                spt=16, render_type="blinn_phong", shading="flat", cull=not two_sided, max_distance=40.0,
+                                                aspect_mode=1, max_depth=0)
+                    img, st = g.render(cfg)
+                    imgs.append((img, st.rays, st.shadow_rays))
+        frames[cull_lists] = imgs
+        g.close()
+    monkeypatch.delenv("RT_LIGHT_CULL")
+    lit = 0
+    for k, ((a, ra, sa), (b, rb, sb)) in enumerate(zip(frames["1"], frames["0"])):
+        assert np.array_equal(bits(a), bits(b)) and (ra, sa) == (rb, sb), k
+        lit += int((a > 1e-6).any())
+    assert lit >= 8  # the light reaches the walls: a visibility bit that differed would show in the pixels
