@@ -1181,9 +1181,10 @@ int device_build(rt_ads* a) {
         BUILD_TRY(hipMemcpyAsync(h_tot + 8, d_flags.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, 0));
         BUILD_TRY(hipStreamSynchronize(0));
         const uint32_t n_int = h_tot[CH_INTERNAL], n_slot = h_tot[CH_SLOTS], n_child = h_tot[CH_CHILDREN], n_child_list = h_tot[CH_CHILD_LIST];
-        if (h_tot[8] != 0) {
+        if (h_tot[8] != 0) {  // the reference's own invariant (octree.cc:124-152: it prints and exits)
+            const uint32_t lost = h_tot[8];  // (cleanup() frees h_tot)
             cleanup();
-            return fail(RT_ERR_BUILD, "octree build: %u triangles of subdivided nodes at depth %u were assigned to no octant", h_tot[8], depth);
+            return fail(RT_ERR_BUILD, "octree build: %u triangles of subdivided nodes at depth %u were assigned to no octant", lost, depth);
         }
         if (rec_base + n_int >= (1u << 24)) {
             cleanup();

@@ -33,3 +33,17 @@ def orc():
 @pytest.fixture(scope="session")
 def scenes(orc):
     return {k: orc.Scene.from_npz(os.path.join(GOLDEN, "scenes", f"cornell_{k}.npz")) for k in CAMERAS}
+
+
+def soup_that_breaks_the_build_invariant():
+    """54,688 random triangles on which Octree::Build's own check fails (octree.cc:124-152: a triangle of a subdivided
+    node passes the triangle/box test of the node but of none of its octants; the reference prints and exits there)."""
+    import numpy as np
+    rs = np.random.RandomState(6085)
+    rs.randint(20, 400), rs.randint(300, 2500), rs.choice([4, 8, 16]), rs.randint(3, 6)  # (the draws tools/light_cull_fuzz.py makes before this one)
+    n_tri = int(rs.randint(20000, 60000))
+    centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+    size = np.exp(rs.uniform(np.log(0.02), np.log(0.4), (n_tri, 1, 1)))
+    pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+    pos[: n_tri // 3, :, 1] = np.round(pos[: n_tri // 3, :, 1])
+    return pos

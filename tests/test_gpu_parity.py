@@ -925,6 +925,23 @@ def test_errors(rt, scenes):
         assert ok.tree_stats()["max_depth"] == 16
 
 
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_build_invariant_failure_is_reported_by_both_builders(rt, builder):
+    """A soup on which Octree::Build's own check fails (a triangle of a subdivided node reaches none of its octants; the
+    reference prints and exits, octree.cc:124-152): both builders return the error, and the handle builds the next scene."""
+    from conftest import soup_that_breaks_the_build_invariant
+    pos = soup_that_breaks_the_build_invariant()
+    g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10, "builder": builder})
+    with pytest.raises(RuntimeError, match="assigned to no octant"):
+        g.Build(pos)
+    with pytest.raises(RuntimeError, match="rt_ads_build"):
+        g.trace_closest([[0, 0, 0]], [[0, 0, 1]])
+    g.Build(pos[:2000])
+    t, tri = g.trace_closest(pos[:8, 0] + [0.0, 0.0, -30.0], np.tile([0.0, 0.0, 1.0], (8, 1)))
+    assert t.shape == (8,)
+    g.close()
+
+
 def test_dropin_behind_reference_ads_interface(scenes, tmp_path):
     """oracle/_ref/ads_dropin_test links the REFERENCE's own Octree sources and this build's GpuOctree subclass
     (raytracer_amd/host/gpu_octree_ads.h) into one program and compares them through the reference's Ads

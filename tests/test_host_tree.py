@@ -184,6 +184,17 @@ def test_empty_and_root_leaf(scenes):
     assert ht.n_nodes == 1 and len(recs) == 0 and len(slots) == 5 and tuple(root) == (0, 5)
 
 
+def test_build_invariant_failure_is_reported(orc):
+    """A triangle that reaches no octant of its subdivided node: the reference prints and exits (octree.cc:124-152), the
+    library returns an error that names the count -- and the oracle agrees that the build fails."""
+    from conftest import soup_that_breaks_the_build_invariant
+    from raytracer_amd.ads import HostTree
+    pos = soup_that_breaks_the_build_invariant()
+    assert pos.shape[0] == 54688
+    with pytest.raises(RuntimeError, match="assigned to no octant"):
+        HostTree(pos, 16, 10)
+
+
 def test_header_symbols_are_exported():
     with open(os.path.join(ROOT, "include", "raytracer_amd.h")) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
