@@ -2,7 +2,7 @@
 """Randomised parity check against the CPU restatement (GPU box): random triangle soups, random materials (reflection,
 refraction, emissive triangles), random octree parameters, cameras, render types, culling, light-sample and pixel-sample
 counts.  Per scene: primary hits (t and triangle bit for bit), ray counts, image within 1/255 (bit-exact for the render
-types without area lights), in the default traversal forms and with RT_CLIP=0 / RT_TRAVERSAL forced on a share of the scenes.
+types without area lights), on every other scene the Search / ray-triangle counters of the instrumented pass, in the default traversal forms and with RT_CLIP=0 / RT_TRAVERSAL forced on a share of the scenes.
 usage: oracle_fuzz.py [N=200] [first seed=1]"""
 import os
 import sys
@@ -56,7 +56,11 @@ for case in range(n_cases):
         continue
     g.set_shading(None, matid, mats)
     cfg = rt.make_render_config(aspect_mode=aspect, **kw)
+    with_stats = case % 2 == 1  # every other scene also runs the instrumented pass (the reference's own counters)
+    g.collect_search_stats(with_stats)
     img, st = g.render(cfg)
+    q = g.query_stats()
+    g.collect_search_stats(False)
     t, tri = g.primary_hits(cfg)
     g.close()
     osc = orc.Scene.from_arrays(pos, None, matid, mats)
@@ -66,6 +70,9 @@ for case in range(n_cases):
     if not np.array_equal(tri, ref_tri): why.append("triangle")
     if not np.array_equal(t.view(np.uint32), ref_t.view(np.uint32)): why.append("t")
     if st.rays != ost.search_calls: why.append(f"rays {st.rays} != {ost.search_calls}")
+    if with_stats and (q["search_node_count"], q["search_leaves_visited"], q["search_return_count"], q["slab_tests"], q["ray_triangle_tests"], q["counted_rays"]) != \
+            (ost.search_nodes, ost.search_leaves, ost.search_returned, ost.slab_tests, ost.tri_tests, ost.search_calls):
+        why.append("counters")
     diff = float(np.nanmax(np.abs(img - ref))) if img.size else 0.0
     exact = rtype in ("distance", "diffusion")
     if (exact and not np.array_equal(img.view(np.uint32), ref.view(np.uint32))) or not (diff <= 1.0 / 255.0): why.append(f"image {diff:g}")
