@@ -352,6 +352,8 @@ struct rt_ads {
     DevBuf<NodeRec> d_light_lane_nodes;   // per-lane form: per light a copy of the node records ...
     DevBuf<float> d_light_lane_geom;      // ... and the geometry of the slots its leaves keep
     bool light_forms_ready = false, light_forms_lane = false;
+    bool lights_merged = false;  // every light has the same forms (one copy of the arrays)
+    bool light_merge = true;     // RT_LIGHT_MERGE=0 at creation: never merge
     // per-lane any-hit passes with per-light trees: launches of more rays than this serve one light per pass, smaller
     // ones keep all lights of a hit side by side (RT_LANE_SIDE_MAX_RAYS)
     uint64_t lane_side_max_rays = 1ull << 22;
@@ -695,6 +697,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
     }
     a->builder = (int)cfg->builder;
     if (const char* e = getenv("RT_LIGHT_CULL")) a->light_cull = !(e[0] == '0');
+    if (const char* e = getenv("RT_LIGHT_MERGE")) a->light_merge = !(e[0] == '0');
     if (const char* e = getenv("RT_LANE_SIDE_MAX_RAYS")) a->lane_side_max_rays = (uint64_t)atoll(e);
     if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
     // the fixed scratch of rt_ads_search_noalloc: its address on this device, looked up with the device current
@@ -847,7 +850,7 @@ int make_cluster_form(rt_ads* a) {
 // (rt_ads_trace_any) or for closest-hit rays: those walk the full lists.
 constexpr uint32_t kMaxLightForms = 64, kMaxLaneLightForms = 8;
 int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
-    a->light_forms_ready = a->light_forms_lane = false;
+    a->light_forms_ready = a->light_forms_lane = a->lights_merged = false;
     a->light_pairs = a->light_pairs_culled = 0;
     if (!a->light_cull) return RT_OK;
     const size_t nl = light_tri.size();
@@ -913,17 +916,44 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         classify(0, n / n_threads);
         for (auto& w : workers) w.join();
     }
+    // Lights that leave out nearly the same triangles -- the two halves of a light quad -- share ONE set of forms that
+    // leaves out what ALL of them leave out (a subset of each light's own set, so the rule holds for every one): half the
+    // memory and cache footprint, and the lights of a hit can be traced side by side through the same arrays.
+    const size_t nl_all = nl;
+    size_t nl_build = nl;
+    if (a->light_merge && nl >= 2) {
+        std::vector<uint8_t> all(culled.begin(), culled.begin() + n);
+        uint64_t most = 0;
+        for (size_t l = 0; l < nl; ++l) {
+            uint64_t cnt = 0;
+            for (uint64_t j = 0; j < n; ++j) {
+                cnt += culled[l * n + j];
+                all[j] &= culled[l * n + j];
+            }
+            most = std::max(most, cnt);
+        }
+        uint64_t common = 0;
+        for (uint8_t c : all) common += c;
+        if (common * 10 >= most * 9) {
+            std::copy(all.begin(), all.end(), culled.begin());
+            culled.resize(n);
+            nl_build = 1;
+            a->lights_merged = true;
+        }
+    }
     for (uint8_t c : culled) a->light_pairs_culled += c;
-    a->light_pairs = (uint64_t)nl * n;
-    std::vector<LightForm> forms(nl);
+    a->light_pairs_culled *= nl_all / nl_build;
+    a->light_pairs = (uint64_t)nl_all * n;
+    const size_t nb = nl_build;  // sets of forms to build
+    std::vector<LightForm> forms(nl_all);
     for (auto& f : forms) memset(&f, 0, sizeof f);
     LeafTri zero;
     memset(&zero, 0, sizeof zero);
     if (have_flat) {  // per light: the triangles in their order, padded to whole blocks with records that list no leaf
         std::vector<LeafTri> all;
-        std::vector<size_t> first(nl);
-        std::vector<uint32_t> count(nl);
-        for (size_t l = 0; l < nl; ++l) {
+        std::vector<size_t> first(nb);
+        std::vector<uint32_t> count(nb);
+        for (size_t l = 0; l < nb; ++l) {
             first[l] = all.size();
             for (const LeafTri& t : a->h_flat_tris)
                 if (!culled[l * n + t.tri]) all.push_back(t);
@@ -933,7 +963,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         for (int k = 0; k < kTriChunk; ++k) all.push_back(zero);  // the pass reads whole blocks
         HIP_TRY(a->d_light_flat.reserve(all.size()));
         HIP_TRY(hipMemcpy(a->d_light_flat.p, all.data(), all.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nl; ++l) {
+        for (size_t l = 0; l < nb; ++l) {
             forms[l].flat_tris = a->d_light_flat.p + first[l];
             forms[l].n_flat_tris = count[l];
         }
@@ -942,9 +972,9 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         const size_t n_rec = a->h_cl_nodes.size();
         std::vector<NodeRec> nodes;
         std::vector<LeafTri> tris;
-        std::vector<size_t> tri_first(nl);
-        nodes.reserve(nl * n_rec);
-        for (size_t l = 0; l < nl; ++l) {
+        std::vector<size_t> tri_first(nb);
+        nodes.reserve(nb * n_rec);
+        for (size_t l = 0; l < nb; ++l) {
             tri_first[l] = tris.size();
             for (size_t r = 0; r < n_rec; ++r) {
                 NodeRec rec = a->h_cl_nodes[r];
@@ -967,7 +997,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         HIP_TRY(a->d_light_cl_tris.reserve(tris.size()));
         HIP_TRY(hipMemcpy(a->d_light_cl_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(a->d_light_cl_tris.p, tris.data(), tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nl; ++l) {
+        for (size_t l = 0; l < nb; ++l) {
             forms[l].cl_nodes = a->d_light_cl_nodes.p + l * n_rec;
             forms[l].cl_tris = a->d_light_cl_tris.p + tri_first[l];
         }
@@ -978,11 +1008,11 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         std::vector<LeafTri> slots(n_slots);
         HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
-        std::vector<NodeRec> all_nodes(nl * n_rec);
-        std::vector<std::vector<float>> geom_of(nl);
-        std::vector<size_t> geom_first(nl);
-        std::vector<uint32_t> root1(nl);
-        std::vector<int> bad(nl, 0);
+        std::vector<NodeRec> all_nodes(nb * n_rec);
+        std::vector<std::vector<float>> geom_of(nb);
+        std::vector<size_t> geom_first(nb);
+        std::vector<uint32_t> root1(nb);
+        std::vector<int> bad(nb, 0);
         // one host thread per light (at most kMaxLaneLightForms)
         auto one_light = [&](size_t l) {
             const uint8_t* cl = culled.data() + l * n;
@@ -1030,23 +1060,23 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         };
         {
             std::vector<std::thread> workers;
-            for (size_t l = 1; l < nl; ++l) workers.emplace_back(one_light, l);
+            for (size_t l = 1; l < nb; ++l) workers.emplace_back(one_light, l);
             one_light(0);
             for (auto& w : workers) w.join();
         }
-        for (size_t l = 0; l < nl; ++l)
+        for (size_t l = 0; l < nb; ++l)
             if (bad[l]) return fail(RT_ERR_BUILD, "internal: the resident tree is not in the layout the per-light copies assume (%d)", bad[l]);
         size_t geom_total = 0;
-        for (size_t l = 0; l < nl; ++l) {
+        for (size_t l = 0; l < nb; ++l) {
             geom_first[l] = geom_total;
             geom_total += geom_of[l].size();
         }
         HIP_TRY(a->d_light_lane_nodes.reserve(all_nodes.size()));
         HIP_TRY(a->d_light_lane_geom.reserve(geom_total));
         HIP_TRY(hipMemcpy(a->d_light_lane_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nl; ++l)
+        for (size_t l = 0; l < nb; ++l)
             HIP_TRY(hipMemcpy(a->d_light_lane_geom.p + geom_first[l], geom_of[l].data(), geom_of[l].size() * sizeof(float), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nl; ++l) {
+        for (size_t l = 0; l < nb; ++l) {
             forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
             forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
             forms[l].lane_root_info1 = root1[l];
@@ -1055,8 +1085,9 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         }
         a->light_forms_lane = true;
     }
-    HIP_TRY(a->d_light_forms.reserve(nl));
-    HIP_TRY(hipMemcpy(a->d_light_forms.p, forms.data(), nl * sizeof(LightForm), hipMemcpyHostToDevice));
+    for (size_t l = nb; l < nl_all; ++l) forms[l] = forms[0];  // (merged: every light points at the one set)
+    HIP_TRY(a->d_light_forms.reserve(nl_all));
+    HIP_TRY(hipMemcpy(a->d_light_forms.p, forms.data(), nl_all * sizeof(LightForm), hipMemcpyHostToDevice));
     a->light_forms_ready = true;
     return RT_OK;
 }
@@ -1829,6 +1860,7 @@ SceneDev scene_dev(const rt_ads* a) {
     S.lights = a->d_lights.p;
     S.n_lights = a->n_lights;
     S.light_forms = (a->light_cull && a->light_forms_ready) ? a->d_light_forms.p : nullptr;
+    S.lights_merged = a->lights_merged ? 1u : 0u;
     return S;
 }
 
@@ -2025,7 +2057,8 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 // (with per-light forms of the tree a per-lane pass, too, serves one light at a time)
                 // ... unless the launch is small: then the lights of a hit stay side by side (a shorter chain of walks per
                 // wave) and every lane walks its own light's tree
-                const bool light_trees = mode_a == MODE_LANE && F.cull && a->light_cull && a->light_forms_lane;
+                // (lights with merged forms walk one tree: side by side, like without the forms)
+                const bool light_trees = mode_a == MODE_LANE && F.cull && a->light_cull && a->light_forms_lane && !a->lights_merged;
                 const bool light_passes = wave_a || (light_trees && (uint64_t)n_hits * a->n_lights * (uint64_t)c->samples_per_triangle > a->lane_side_max_rays);
                 while (!light_passes && (1ull << gshift) < ((uint64_t)a->n_lights << pshift) && gshift < 6) ++gshift;
                 if (gshift < pshift) gshift = pshift < 6 ? pshift : 6;  // a group never exceeds the wave

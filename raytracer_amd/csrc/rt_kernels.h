@@ -184,6 +184,7 @@ struct SceneDev {
     const MatDev* mats;
     const LightDev* lights;
     uint32_t n_lights;
+    uint32_t lights_merged;        // all lights share one set of forms (light_forms[l] are equal): see make_light_forms
     const LightForm* light_forms;  // per light, or nullptr (culling off at creation, too many lights, no such forms)
 };
 
@@ -616,10 +617,11 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
             DevOctree T = S.tree;
             // (the wave-together forms are always launched with one light per pass, group <= samples per light; the
             // per-lane form is when the scene has per-light forms)
-            if (S.light_forms != nullptr && gshift <= pshift) {
+            // (lights whose forms were merged share one set of arrays: then the lights of a hit may stay side by side)
+            if (S.light_forms != nullptr && (S.lights_merged != 0u || gshift <= pshift)) {
                 // (read through the constant address space: scalar loads, the pointers stay in scalar registers)
-                const RT_CONST LightForm& lf =
-                    *(const RT_CONST LightForm*)(uintptr_t)(S.light_forms + (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift)));
+                const uint32_t l_form = S.lights_merged != 0u ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(q0 >> pshift));
+                const RT_CONST LightForm& lf = *(const RT_CONST LightForm*)(uintptr_t)(S.light_forms + l_form);
                 if (MODE == MODE_LANE && lf.lane_nodes != nullptr) {
                     T.nodes = lf.lane_nodes;
                     T.slot_geom = lf.lane_slot_geom;
