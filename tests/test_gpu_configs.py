@@ -300,15 +300,26 @@ def test_frames_in_flight_equal_blocking_frames(rt, scenes, monkeypatch):
         hip.free(out, *bufs)
 
 
-@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered", "big_tree_per_lane", "soup_two_sided", "soup_many_lights"])
+@pytest.mark.parametrize("case", ["original", "sphere", "soup_small_tree", "soup_clustered", "big_tree_per_lane", "big_tree_own_forms_side_by_side",
+                                  "big_tree_own_forms_light_passes", "original_own_forms", "soup_two_sided", "soup_many_lights"])
 def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, case):
     """With back-face culling on, the any-hit passes towards a light walk lists without the triangles that hold the whole
     light in front of them (they can never be accepted occluders of a ray that ends on it).  The frames must be the ones
     of the full lists bit for bit -- same image, same ray counts -- and the oracle's within the shading tolerance, on the
     two shipped scenes, on random triangle soups with emissive triangles at arbitrary angles (small-tree and clustered
     form) and on a big tree, whose per-lane walks get per-light node records and slot geometry (octants and subtrees
-    left without a triangle become empty); and the lists must really leave something out."""
+    left without a triangle become empty); and the lists must really leave something out.  The halves of the Cornell
+    light quad share one set of forms; the *_own_forms cases give every light its own (RT_LIGHT_MERGE=0), on the big tree
+    once with the lights of a hit side by side (every lane in its own light's tree) and once with one light per pass."""
     rows = None
+    own_forms = "own_forms" in case
+    for k in ("RT_LIGHT_MERGE", "RT_LANE_SIDE_MAX_RAYS"):
+        monkeypatch.delenv(k, raising=False)
+    if own_forms:
+        monkeypatch.setenv("RT_LIGHT_MERGE", "0")
+    if case == "big_tree_own_forms_light_passes":
+        monkeypatch.setenv("RT_LANE_SIDE_MAX_RAYS", "0")
+    case = {"big_tree_own_forms_side_by_side": "big_tree_per_lane", "big_tree_own_forms_light_passes": "big_tree_per_lane", "original_own_forms": "original"}.get(case, case)
     if case in ("original", "sphere"):
         sc = scenes[case]
         pos, nrm, matid, mats = sc.pos, (sc.norm if sc.has_normals else None), sc.matid, sc.materials

@@ -43,6 +43,11 @@ for case in range(first_case, n_cases):
               max_distance=40.0, aspect_mode=1, seed=int(rs.randint(1, 1 << 30)))
     cfg = rt.make_render_config(**kw)
     out = {}
+    # how lights that do not share forms are served on big trees, in rotation: by the library's own choice, always one light
+    # per pass, never merged
+    for k in ("RT_LANE_SIDE_MAX_RAYS", "RT_LIGHT_MERGE"):
+        os.environ.pop(k, None)
+    os.environ.update([{}, {"RT_LANE_SIDE_MAX_RAYS": "0"}, {"RT_LIGHT_MERGE": "0"}, {"RT_LIGHT_MERGE": "0", "RT_LANE_SIDE_MAX_RAYS": "0"}][(case // 3) % 4])
     for flag in ("1", "0"):
         os.environ["RT_LIGHT_CULL"] = flag
         g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
