@@ -184,6 +184,10 @@ def kernel_summary(acc, steps, work):
         out["k_tail"] = {"launches": acc["tail_launches"], "avg_launch_ms": acc["tail_ms"] / acc["tail_launches"],
                          "ms_per_frame": acc["tail_ms"] / steps}
     out["k_shadow"]["Mrays_per_s"] = shadow_rate / 1e6
+    if acc["shadow_rays_not_traced"]:
+        # shadow rays (counted like the reference casts them) whose light sample adds a zero to the colour whether it is
+        # visible or not: answered without a walk (rt_render_stats.shadow_rays_not_traced)
+        out["k_shadow"]["rays_not_traced_frac"] = acc["shadow_rays_not_traced"] / max(acc["all_shadow_rays"], 1)
     out["k_closest"]["Mrays_per_s"] = closest_rate / 1e6
     if work is not None:
         for name, rate, key in (("k_shadow", shadow_rate, "any_hit"), ("k_closest", closest_rate, "closest_hit")):
@@ -196,7 +200,8 @@ def kernel_summary(acc, steps, work):
 
 def new_acc():
     return dict(tail_ms=0.0, tail_launches=0, rays=0, shade_ms=0.0, closest_ms=0.0, shadow_ms=0.0, shade_launches=0, closest_launches=0, shadow_launches=0,
-                shade_launches_all=0, closest_launches_all=0, shadow_launches_all=0, shadow_rays=0, closest_rays=0)
+                shade_launches_all=0, closest_launches_all=0, shadow_launches_all=0, shadow_rays=0, closest_rays=0, all_shadow_rays=0,
+                shadow_rays_not_traced=0)
 
 
 def add_stats(acc, st):
@@ -216,6 +221,8 @@ def add_stats(acc, st):
     acc["closest_launches_all"] += st.launches_closest
     acc["shadow_rays"] += st.timed_shadow_rays
     acc["closest_rays"] += st.timed_closest_rays
+    acc["all_shadow_rays"] += st.shadow_rays
+    acc["shadow_rays_not_traced"] += st.shadow_rays_not_traced
 
 
 def pmc_file():

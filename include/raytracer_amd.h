@@ -220,6 +220,12 @@ typedef struct rt_render_stats {
      * recursion (closest hits, shadow rays, shading of every deeper level) runs as ONE launch; its time and count. */
     float ms_tail;
     uint32_t launches_tail;
+    /* Shadow rays (counted in shadow_rays, as the reference casts them) that were answered without a walk: the light
+     * sample they test adds a zero to the hit's colour whether it is visible or not -- the light faces away from the
+     * hit, or the surface faces away from the light and has no specular colour -- so it is reported as shadowed and the
+     * image has the same bits.  Flat shading, finite lights and materials, big trees (per-lane walks) only;
+     * RT_SKIP_UNLIT=0 at rt_ads_create traces every ray. */
+    uint64_t shadow_rays_not_traced;
 } rt_render_stats;
 
 /* Renderer::RenderScene's hot loop (src/Renderer/renderer.cc:37-52) on the device: primary rays

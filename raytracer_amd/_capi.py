@@ -61,7 +61,7 @@ class RenderStats(C.Structure):
                 ("ms_closest", C.c_float), ("ms_shadow", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
                 ("launches_closest", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32),
                 ("timed_closest_rays", C.c_uint64), ("timed_shadow_rays", C.c_uint64),
-                ("ms_tail", C.c_float), ("launches_tail", C.c_uint32)]
+                ("ms_tail", C.c_float), ("launches_tail", C.c_uint32), ("shadow_rays_not_traced", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

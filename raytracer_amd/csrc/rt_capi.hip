@@ -346,6 +346,7 @@ struct rt_ads {
     std::vector<LeafTri> h_flat_tris, h_cl_tris;
     std::vector<NodeRec> h_cl_nodes;
     bool light_cull = true;  // RT_LIGHT_CULL=0 at creation: every light's any-hit passes walk the full lists
+    bool skip_unlit = true;  // RT_SKIP_UNLIT=0 at creation: shadow rays whose answer cannot change the image are traced too
     DevBuf<LightForm> d_light_forms;
     DevBuf<LeafTri> d_light_flat, d_light_cl_tris;
     DevBuf<NodeRec> d_light_cl_nodes;
@@ -697,6 +698,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
     }
     a->builder = (int)cfg->builder;
     if (const char* e = getenv("RT_LIGHT_CULL")) a->light_cull = !(e[0] == '0');
+    if (const char* e = getenv("RT_SKIP_UNLIT")) a->skip_unlit = !(e[0] == '0');
     if (const char* e = getenv("RT_LIGHT_MERGE")) a->light_merge = !(e[0] == '0');
     if (const char* e = getenv("RT_LANE_SIDE_MAX_RAYS")) a->lane_side_max_rays = (uint64_t)atoll(e);
     if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
@@ -1767,6 +1769,37 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         const float* f = materials + (size_t)material_ids[light_tri[l]] * 18;
         L.emission[0] = f[12]; L.emission[1] = f[13]; L.emission[2] = f[14];
     }
+    // Which shadow rays need no answer (shadow_ray_idle in rt_kernels.h): the rule multiplies zeros with the lights'
+    // and materials' numbers, so those must be finite, and moderate enough that no product of them overflows --
+    // I_l = emission * area * cos / (spt * dist^2 + 1e-9) times a diffuse colour stays below 1e30.
+    std::vector<uint32_t> mat_dark(mats.size(), 0);
+    {
+        bool lights_fine = a->skip_unlit;
+        double max_e = 0.0, max_area = 0.0, max_diffuse = 1.0;
+        for (size_t l = 0; l < light_tri.size(); ++l) {
+            const LightDev& L = lights[l];
+            for (int k = 0; k < 3; ++k) {
+                lights_fine = lights_fine && std::isfinite(L.n[k]) && std::isfinite(L.emission[k]) && std::isfinite(L.a[k]) &&
+                              std::isfinite(L.e1[k]) && std::isfinite(L.e2[k]);
+                max_e = std::max(max_e, (double)std::fabs(L.emission[k]));
+            }
+            lights_fine = lights_fine && std::isfinite(L.area);
+            max_area = std::max(max_area, (double)L.area);
+        }
+        for (uint32_t m = 0; m < n_mat; ++m)
+            for (int k = 0; k < 3; ++k)
+                if (std::isfinite(mats[m].diffuse[k])) max_diffuse = std::max(max_diffuse, (double)std::fabs(mats[m].diffuse[k]));
+        lights_fine = lights_fine && max_e * max_area * 1e9 * max_diffuse < 1e30;
+        for (uint32_t m = 0; m < n_mat && lights_fine; ++m) {
+            const MatDev& d = mats[m];
+            bool fine = std::isfinite(d.shininess) && d.shininess >= 0.0f && d.shininess <= 1e6f;
+            for (int k = 0; k < 3; ++k) fine = fine && std::isfinite(d.diffuse[k]) && std::isfinite(d.specular[k]) && std::isfinite(d.emission[k]);
+            if (!fine) continue;
+            mat_dark[m] = kDarkFinite;
+            if (d.emission[0] == 0.0f && d.emission[1] == 0.0f && d.emission[2] == 0.0f) mat_dark[m] |= kDarkEmissionZero;
+            if (d.specular[0] == 0.0f && d.specular[1] == 0.0f && d.specular[2] == 0.0f) mat_dark[m] |= kDarkSpecZero;
+        }
+    }
     std::vector<TriShade> ts(std::max<uint64_t>(n, 1));
     for (uint64_t i = 0; i < n; ++i) {
         const float* p = a->positions.data() + i * 9;
@@ -1777,7 +1810,8 @@ int rt_scene_set_shading(rt_ads* a, const float* normals, const int32_t* materia
         t.mat = material_ids[i];
         t.light_eq = -1;
         t.spawn = (mats[material_ids[i]].has_specular ? 1u : 0u) + (mats[material_ids[i]].has_transmittance ? 1u : 0u);
-        t.pad[0] = t.pad[1] = 0;
+        t.dark = (std::isfinite(nn.x) && std::isfinite(nn.y) && std::isfinite(nn.z)) ? mat_dark[material_ids[i]] : 0u;
+        t.pad = 0;
         for (size_t l = 0; l < light_tri.size(); ++l) {
             const uint32_t lt = light_tri[l];
             if (tri_equal(a->positions.data() + (size_t)lt * 9, normals ? normals + (size_t)lt * 9 : nullptr, p, normals ? normals + i * 9 : nullptr)) {
@@ -1971,7 +2005,7 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
     x.slot_seq = seq_base + (uint32_t)c->samples_per_pixel + 1u;  // the next frame starts beyond every sequence number of this one
     hipLaunchKernelGGL(k_frame_begin, dim3(1), block, 0, stream, x.d_counters.p, max_levels, x.h_slots, seq_base, x.d_totals.p);
     HIP_TRY(hipGetLastError());
-    x.h_totals->secondary_rays = x.h_totals->shadow_rays = x.h_totals->deepest_level = 0;
+    x.h_totals->secondary_rays = x.h_totals->shadow_rays = x.h_totals->deepest_level = x.h_totals->idle_shadow_rays = 0;
     uint32_t level_seq[kMaxLevels];
     for (auto& q : level_seq) q = seq_base;
     const bool lit = (c->render_type == RT_RENDER_PHONG || c->render_type == RT_RENDER_BLINN_PHONG) && a->n_lights > 0 && c->samples_per_triangle > 0;
@@ -2153,6 +2187,7 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
     }
     st.secondary_rays = x.h_totals->secondary_rays;  // written by the last k_roll_counters, complete after the synchronisation above
     st.shadow_rays = x.h_totals->shadow_rays;
+    st.shadow_rays_not_traced = x.h_totals->idle_shadow_rays;
     st.levels = std::max(st.levels, (uint32_t)x.h_totals->deepest_level);
     st.rays = st.primary_rays + st.secondary_rays + st.shadow_rays;
     st_out = st;
@@ -2237,6 +2272,7 @@ int rt_render(rt_ads* a, const rt_render_config* c, float* out_rgb, int mem, rt_
         st.ms_total = std::max(st.ms_total, s.ms_total);
         st.launches_closest += s.launches_closest; st.launches_shadow += s.launches_shadow; st.launches_shade += s.launches_shade;
         st.launches_tail += s.launches_tail;
+        st.shadow_rays_not_traced += s.shadow_rays_not_traced;
         st.timed_closest_rays += s.timed_closest_rays; st.timed_shadow_rays += s.timed_shadow_rays;
     }
     if (mem == RT_MEM_HOST) {

@@ -118,7 +118,8 @@ struct alignas(16) TriShade {  // per triangle in Build order
     int32_t mat;               // Triangle::material_id
     int32_t light_eq;          // first light l with lights[l] == triangle (src/triangle.h:15-19), else -1
     uint32_t spawn;            // secondary rays a hit can spawn at most: non-zero specular + non-zero transmittance (renderer.cc:179,185)
-    int32_t pad[2];
+    uint32_t dark;             // kDark* bits: which shadow rays of a hit on this triangle need no answer (shadow_ray_idle)
+    int32_t pad;
 };
 static_assert(sizeof(TriShade) == 32, "");
 
@@ -207,8 +208,12 @@ struct FrameParams {
 // pinned host memory, 64 bits, 0 = nobody listens) are set up by k_frame_begin and live for the whole frame; keeping them
 // here rather than in kernel arguments keeps the traversal kernels' scalar register count where it was.
 // CNT_DEEPEST (k_tail): the deepest recursion level a path of the fused tail reached, + 1.
+// CNT_IDLE: shadow rays of the level that were not traced (shadow_ray_idle); they are part of CNT_SHADOW.  Every wave
+// of the any-hit pass may add to it, so it is kCntIdleLines partial sums in lines of their own (a wave picks one by its
+// block index).
+constexpr uint32_t kCntIdleLines = 8;
 enum { CNT_WORK = 0, CNT_NEXT = 32, CNT_SHADOW_LO = 64, CNT_SHADOW_HI = 65, CNT_SPAWN = 96, CNT_TICKET = 128, CNT_SEQ = 129,
-       CNT_SLOT_LO = 130, CNT_SLOT_HI = 131, CNT_DEEPEST = 132, CNT_WORDS = 160 };
+       CNT_SLOT_LO = 130, CNT_SLOT_HI = 131, CNT_DEEPEST = 132, CNT_IDLE = 160, CNT_WORDS = 160 + 32 * kCntIdleLines };
 
 // What the host needs to know about a level to size the launches that follow, written by the last block of the
 // level's closest-hit pass straight into pinned host memory (flag last, system-scope release): the host polls the
@@ -225,7 +230,7 @@ static_assert(sizeof(LevelSlot) == 32, "");
 
 // Frame totals kept on the device between the samples of a frame (k_roll_counters) and mirrored into pinned host memory.
 struct FrameTotals {
-    unsigned long long secondary_rays, shadow_rays, deepest_level;
+    unsigned long long secondary_rays, shadow_rays, deepest_level, idle_shadow_rays;
 };
 
 // ---- helpers ---------------------------------------------------------------------------------------------------
@@ -547,6 +552,30 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
     return (la + (le1 * uu)) + (le2 * vv);
 }
 
+// Shadow rays that need no answer.  A visible light sample adds c = (I_a + I_d) + I_s (+ the material's emission with
+// Phong, renderer.cc:264-266) to the hit's colour, I_l = emission * w with w = area * max(0, dot(n_l, -d_l)) / (...)
+// (renderer.cc:220-240).  Where every term of c is a zero whatever the sample's visibility, the sum -- which starts at
+// +0 -- is the same bits with or without the sample, so its shadow ray is not traced and the sample counts as shadowed:
+//   A. the light faces away from the hit (max(0, dot(n_l, -d_l)) is 0): w = 0, so I_l, I_a, I_d and I_s are zeros;
+//   B. the surface faces away from the light (max(0, dot(N, d_l)) is 0) and its specular colour is zero: I_d and I_s
+//      are zeros (Phong's specular term has no such factor, hence the condition on the colour).
+// "Zero times x is zero" needs x finite: the host sets the bits only for scenes whose lights and materials are finite
+// and moderate (rt_scene_set_shading), the shininess in [0, 1e6] (a finite power), and here the ray must have a finite
+// length.  N is the face normal: flat shading only.  Both tests use the very expressions of the shading code, so a
+// sample is skipped exactly when that code would multiply by its zero.  On a closed mesh the skipped rays are the
+// expensive ones: with back faces culled a ray that starts on the far side of a sphere runs through its whole interior.
+constexpr uint32_t kDarkFinite = 1u;        // rule A may be used (and rule B with kDarkSpecZero)
+constexpr uint32_t kDarkEmissionZero = 2u;  // the material's emission is zero: needed with Phong
+constexpr uint32_t kDarkSpecZero = 4u;      // the material's specular colour is zero
+__device__ __forceinline__ bool shadow_ray_idle(const FrameParams& F, uint32_t dark, f3 N, f3 n_l, f3 d_l, float dist) {
+    if (!(dark & kDarkFinite) || F.shading_type != 0) return false;
+    if (F.render_type == 2 && !(dark & kDarkEmissionZero)) return false;
+    if (!(dist < RT_INF)) return false;
+    const bool light_faces_away = !(0.0f < dot(n_l, -d_l));
+    const bool surface_faces_away = !(0.0f < dot(N, d_l)) && (dark & kDarkSpecZero) != 0u;
+    return light_faces_away || surface_faces_away;
+}
+
 // The any-hit pass: every shadow / area-light ray of every hit of one level (renderer.cc:217-219, 288-313).
 // A hit owns 2^gshift neighbouring lanes.  The (light, sample) pairs of the hit are numbered q = light * 2^pshift +
 // sample (2^pshift = the samples-per-light count rounded up to a power of two) and lane `sub` of the group traces
@@ -579,16 +608,24 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
     uint32_t pixel, node_id;
     load_ray(F, rays, level, i, active ? n : 0, valid, o, d, pixel, node_id);
     valid = valid && active;
+    // Rays that need no answer (shadow_ray_idle) are left out where every lane walks its own ray: the lanes they free
+    // take over other rays' subtrees or tasks, and waves without a ray end at once.  A wave that walks its rays together
+    // only gains if all 64 are left out, which does not pay for the test.
+    constexpr bool kSkipIdle = MODE == MODE_LANE || MODE == MODE_POOL;
     float t = 0.0f;
-    int32_t light_eq = -1;
+    uint32_t tri = 0;
     if (valid) {
         t = hit_t[i];
-        light_eq = S.tri_shade[hit_tri[i]].light_eq;
+        tri = (uint32_t)hit_tri[i];
     }
     const f3 P = o + (d * t);  // renderer.cc:146
     const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
     // renderer.cc:212-214: the light loop ends at the light the hit triangle itself is
-    const uint32_t lights_traced = !valid ? 0u : ((light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights);
+    uint32_t lights_traced = 0;
+    if constexpr (!kSkipIdle) {
+        const int32_t light_eq = valid ? S.tri_shade[tri].light_eq : -1;
+        lights_traced = !valid ? 0u : ((light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights);
+    }
     // the lanes whose ballot bits form one visibility word: the samples of one light, or 32 of them
     const uint32_t per_light = 1u << pshift;
     const uint32_t word_lanes = per_light < 32u ? per_light : 32u;
@@ -599,8 +636,19 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
     for (uint32_t q0 = 0; q0 < q_end; q0 += group) {
         const uint32_t q = q0 + sub;
         const uint32_t l = q >> pshift, smp = q & (per_light - 1u);
+        uint32_t dark = 0;
+        f3 N = mk(0, 0, 0);
+        if constexpr (kSkipIdle) {
+            // The hit triangle's record is read again in every pass (the empty statement keeps the read inside the
+            // loop): the triangle index is one register to carry through the walks below, the record's fields five.
+            asm volatile("" : "+v"(tri));
+            const TriShade ts = S.tri_shade[tri];
+            lights_traced = !valid ? 0u : ((ts.light_eq >= 0 && (uint32_t)ts.light_eq < S.n_lights) ? (uint32_t)ts.light_eq : S.n_lights);
+            dark = ts.dark;
+            N = mk(ts.nx, ts.ny, ts.nz);
+        }
         const bool lit = l < lights_traced;
-        const bool on = lit && smp < (uint32_t)F.spt;
+        bool on = lit && smp < (uint32_t)F.spt;
         const lanemask on_mask = ballot64(on);
         if (on_mask == 0) continue;
         // one light per pass (group == samples per light): its record is wave-uniform and comes through scalar loads
@@ -611,6 +659,15 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         const f3 to_l = p_l - P;
         const float dist = length(to_l);
         const f3 d_l = normalize(to_l);
+        // samples that add nothing to the hit's colour whether visible or not: not traced, reported as shadowed
+        lanemask idle_mask = 0;
+        if constexpr (kSkipIdle) {
+            const bool idle = on && shadow_ray_idle(F, dark, N, mk(L.n[0], L.n[1], L.n[2]), d_l, dist);
+            idle_mask = ballot64(idle);
+            on = on && !idle;
+            if (idle_mask != 0 && __lane_id() == 0)
+                atomicAdd(&counters[CNT_IDLE + 32u * (blockIdx.x % kCntIdleLines)], (uint32_t)__builtin_popcountll(idle_mask));
+        }
         HitState h;
         if constexpr (CULL && (MODE == MODE_WAVE || MODE == MODE_CLUSTER || MODE == MODE_LANE)) {
             // one light per pass: the wave walks that light's own lists (wave-uniform record, scalar loads)
@@ -655,7 +712,7 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
         } else {
             trace<true, CULL, MODE, FAST>(S.tree, lds[threadIdx.x >> 6], opts, on, P, d_l, dist, h);
         }
-        const lanemask unshadowed = on_mask & ~h.found;
+        const lanemask unshadowed = on_mask & ~h.found & ~idle_mask;
         const uint32_t word = smp >> 5;
         if (lit && writer && word < words)
             vis[((size_t)l * words + word) * n_work + j] = (uint32_t)(unshadowed >> word_first_lane) & word_mask;
@@ -946,7 +1003,7 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
     }
     const uint32_t first_node_id = node_id;
     bool live = carrier;
-    uint32_t depth_n = 0, n_next = 0;
+    uint32_t depth_n = 0, n_next = 0, n_idle = 0;
     unsigned long long n_shadow = 0;
     for (uint32_t level = first;; ++level) {
         // ---- closest hit (renderer.cc:116-142)
@@ -955,16 +1012,21 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
         const bool hit = live && !(h.t == RT_INF);
         const f3 P = o + (d * h.t);  // renderer.cc:146
         const uint32_t pre = rng_prefix(F.seed, pixel, F.spp_sample, node_id);
-        uint32_t lights_traced = 0;
+        uint32_t lights_traced = 0, dark = 0;
+        f3 N = mk(0, 0, 0);
         if (hit && lit) {  // renderer.cc:212-214: the light loop ends at the light the hit triangle itself is
-            const int32_t light_eq = S.tri_shade[h.tri].light_eq;
-            lights_traced = (light_eq >= 0 && (uint32_t)light_eq < S.n_lights) ? (uint32_t)light_eq : S.n_lights;
+            const TriShade ts = S.tri_shade[h.tri];
+            lights_traced = (ts.light_eq >= 0 && (uint32_t)ts.light_eq < S.n_lights) ? (uint32_t)ts.light_eq : S.n_lights;
+            dark = ts.dark;
+            N = mk(ts.nx, ts.ny, ts.nz);
         }
         // ---- the hit's shadow rays (renderer.cc:217-219, 288-313), one per lane of the group
         lanemask vis_bits = 0;
         if (lit && ballot64(lights_traced != 0u) != 0) {
             const f3 gP = mk(__shfl(P.x, (int)lead, 64), __shfl(P.y, (int)lead, 64), __shfl(P.z, (int)lead, 64));
             const uint32_t g_pre = __shfl(pre, (int)lead, 64), g_traced = __shfl(lights_traced, (int)lead, 64);
+            const uint32_t g_dark = __shfl(dark, (int)lead, 64);
+            const f3 gN = mk(__shfl(N.x, (int)lead, 64), __shfl(N.y, (int)lead, 64), __shfl(N.z, (int)lead, 64));
             const uint32_t l = sub >> pshift, smp = sub & (per_light - 1u);
             const bool on = lane_ok && l < g_traced && smp < (uint32_t)F.spt;
             const LightDev& L = S.lights[on ? l : 0u];
@@ -976,17 +1038,20 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
             // every lane walks the tree of its own light where the scene has per-light trees (LightForm)
             DevOctree T = S.tree;
             uint32_t rec_base = 0, slot_base = 0;
-            bool walk = on;
+            // (samples that add nothing to the hit's colour whether visible or not are not traced: shadow_ray_idle)
+            const bool idle = on && shadow_ray_idle(F, g_dark, gN, mk(L.n[0], L.n[1], L.n[2]), d_l, dist);
+            n_idle += idle ? 1u : 0u;
+            bool walk = on && !idle;
             if (CULL && S.light_forms != nullptr && S.light_forms[0].lane_nodes != nullptr) {
                 const LightForm& lf = S.light_forms[on ? l : 0u];
                 T.nodes = S.light_forms[0].lane_nodes;
                 T.slot_geom = S.light_forms[0].lane_slot_geom;
                 rec_base = lf.lane_rec_base;
                 slot_base = lf.lane_slot_base;
-                walk = on && lf.lane_root_info1 != 0u;  // (0: nothing can occlude that light)
+                walk = walk && lf.lane_root_info1 != 0u;  // (0: nothing can occlude that light)
             }
             trace<true, CULL, MODE_LANE, FAST, true>(T, lds[0], opts, walk, gP, d_l, dist, hs, rec_base, slot_base);
-            const lanemask unshadowed = ballot64(on) & ~hs.found;
+            const lanemask unshadowed = ballot64(on && !idle) & ~hs.found;
             vis_bits = (unshadowed >> lead) & group_mask;
         }
         // ---- shading, recursion gate, the next ray (renderer.cc:144-192)
@@ -1032,6 +1097,7 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         n_next += __shfl_xor(n_next, s, 64);
+        n_idle += __shfl_xor(n_idle, s, 64);
         n_shadow += __shfl_xor(n_shadow, s, 64);
         const uint32_t other = __shfl_xor(deepest, s, 64);
         deepest = deepest > other ? deepest : other;
@@ -1039,6 +1105,7 @@ __global__ void __launch_bounds__(64) k_tail(SceneDev S, FrameParams F, uint32_t
     if (lane == 0) {
         if (n_next) atomicAdd(&counters[CNT_NEXT], n_next);
         if (n_shadow) atomicAdd((unsigned long long*)&counters[CNT_SHADOW_LO], n_shadow);
+        if (n_idle) atomicAdd(&counters[CNT_IDLE + 32u * (blockIdx.x % kCntIdleLines)], n_idle);
         if (deepest) atomicMax(&counters[CNT_DEEPEST], deepest);
     }
 }
@@ -1087,10 +1154,10 @@ __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams F, const Nod
 // the host to read after the frame) and zeroes the per-level counters for the next sample.  One block.
 __global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ counters, uint32_t levels, FrameTotals* __restrict__ totals,
                                                        FrameTotals* __restrict__ host_totals) {
-    __shared__ unsigned long long s_next, s_shadow;
+    __shared__ unsigned long long s_next, s_shadow, s_idle;
     __shared__ uint32_t s_deepest;
     if (threadIdx.x == 0) {
-        s_next = s_shadow = 0ull;
+        s_next = s_shadow = s_idle = 0ull;
         s_deepest = 0u;
     }
     __syncthreads();
@@ -1099,12 +1166,14 @@ __global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ co
         atomicAdd(&s_next, (unsigned long long)c[CNT_NEXT]);
         atomicAdd(&s_shadow, (unsigned long long)c[CNT_SHADOW_LO] | ((unsigned long long)c[CNT_SHADOW_HI] << 32));
         atomicMax(&s_deepest, c[CNT_DEEPEST]);
+        for (uint32_t k = 0; k < kCntIdleLines; ++k) atomicAdd(&s_idle, (unsigned long long)c[CNT_IDLE + 32u * k]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         FrameTotals t = *totals;
         t.secondary_rays += s_next;
         t.shadow_rays += s_shadow;
+        t.idle_shadow_rays += s_idle;
         t.deepest_level = t.deepest_level > s_deepest ? t.deepest_level : (unsigned long long)s_deepest;
         *totals = t;
         *host_totals = t;
@@ -1114,6 +1183,7 @@ __global__ void __launch_bounds__(256) k_roll_counters(uint32_t* __restrict__ co
     for (uint32_t L = threadIdx.x; L < levels; L += blockDim.x) {
         uint32_t* c = counters + (size_t)L * CNT_WORDS;
         c[CNT_WORK] = c[CNT_NEXT] = c[CNT_SHADOW_LO] = c[CNT_SHADOW_HI] = c[CNT_SPAWN] = c[CNT_TICKET] = c[CNT_DEEPEST] = 0u;
+        for (uint32_t k = 0; k < kCntIdleLines; ++k) c[CNT_IDLE + 32u * k] = 0u;
     }
 }
 
@@ -1130,7 +1200,7 @@ __global__ void __launch_bounds__(256) k_frame_begin(uint32_t* __restrict__ coun
         c[CNT_SLOT_LO] = (uint32_t)p;
         c[CNT_SLOT_HI] = (uint32_t)((uint64_t)p >> 32);
     }
-    if (threadIdx.x == 0 && totals) totals->secondary_rays = totals->shadow_rays = totals->deepest_level = 0ull;
+    if (threadIdx.x == 0 && totals) totals->secondary_rays = totals->shadow_rays = totals->deepest_level = totals->idle_shadow_rays = 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_primary_hits(FrameParams F, const float* __restrict__ hit_t, const int32_t* __restrict__ hit_tri,

@@ -17,6 +17,7 @@ FORMS = {
     "lane": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "lane"},
     "pool": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"},
     "full_lists": {"RT_LIGHT_CULL": "0"},                                   # no per-light lists: every any-hit pass walks everything
+    "every_ray": {"RT_SKIP_UNLIT": "0"},                                    # shadow rays that cannot change the image are traced too
 }
 
 
@@ -32,7 +33,7 @@ def bits(a):
 
 def build(rt, sc, monkeypatch=None, form="auto", builder="auto"):
     if monkeypatch is not None:
-        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_LIGHT_CULL"):
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_LIGHT_CULL", "RT_SKIP_UNLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in FORMS[form].items():
             monkeypatch.setenv(k, v)
@@ -71,12 +72,12 @@ def test_original_spp64_spt32_full_size_properties(rt, orc, scenes, monkeypatch)
     sc = scenes["original"]
     kw = dict(fov=0.6, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong", shading="flat", **CAMERAS["original"])
     out = {}
-    for form in ("auto", "general", "full_lists"):
+    for form in ("auto", "general", "full_lists", "every_ray"):
         g = build(rt, sc, monkeypatch, form)
         img = np.zeros((2160, 3840, 3), np.float32)
         _, st = g.render(rt.make_render_config(band_rank=3, band_world=8, **kw), out=img)
         out[form] = (img, st.rays, st.shadow_rays)
-    for form in ("general", "full_lists"):
+    for form in ("general", "full_lists", "every_ray"):
         assert np.array_equal(bits(out["auto"][0]), bits(out[form][0])) and out["auto"][1:] == out[form][1:], form
     img = out["auto"][0]
     # band 3 = rows 24..31 belong to rank 3 of 8; rows 0..23 do not and must be untouched
@@ -389,6 +390,86 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
     else:
         ref, _, _, _ = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=rows, **okw), want_hits=False)
         assert np.abs(frames["1"][0][rows[0]:rows[1]] - ref[rows[0]:rows[1]]).max() <= 1.0 / 255.0
+
+
+@pytest.mark.parametrize("walk", ["lane", "pool"])
+@pytest.mark.parametrize("case", ["original_blinn", "original_phong", "sphere_flat_blinn", "sphere_flat_phong", "sphere_smooth", "big_tree_phong",
+                                  "soup_phong", "soup_blinn_two_sided", "soup_odd_materials", "soup_huge_light"])
+def test_shadow_rays_without_effect_change_no_pixel(rt, orc, scenes, monkeypatch, case, walk):
+    """A light sample whose contribution is a zero whether it is visible or not -- the light faces away from the hit, or
+    the surface faces away from the light and has no specular colour -- gets no shadow ray (flat shading, finite and
+    moderate lights and materials, no material emission under Phong).  The frames must be those of RT_SKIP_UNLIT=0, which
+    traces every ray, bit for bit, with the same ray counts (the counts are the reference's, skipped rays included):
+    on the shipped scenes with both lit render types (the Sphere scene has reflecting and refracting materials, so the
+    deeper levels see the rule as well; smooth shading must not use it at all), on a big tree (per-lane walks and the
+    fused tail), on triangle soups with lights at arbitrary angles, two-sided, and with materials and lights the rule
+    must keep away from: infinite and NaN colours, a negative shininess, an emission that overflows a product.  The rule
+    is applied where every lane walks its own ray (per-lane and task-pool forms, the fused tail), so the small scenes are
+    made to use those forms."""
+    from test_gpu_parity import synthetic_scene
+    monkeypatch.setenv("RT_DISABLE_SMALL_TREE", "1")
+    monkeypatch.setenv("RT_TRAVERSAL", walk)
+    nrm = None
+    mb, md = 16, 10
+    if case.startswith("original") or case.startswith("sphere"):
+        name = case.split("_")[0]
+        sc = scenes[name]
+        pos, matid, mats = sc.pos, sc.matid, sc.materials
+        smooth = case == "sphere_smooth"
+        if smooth:
+            nrm = sc.norm
+        kw = dict(fov=0.6, width=200, height=150, spt=5, render_type="phong" if case.endswith("phong") else "blinn_phong",
+                  shading="smooth" if smooth else "flat", max_depth=4, aspect_mode=1, **CAMERAS[name])  # (true aspect ratio: floor and ceiling in view)
+    elif case == "big_tree_phong":
+        sy = synthetic_scene(6)  # 81,954 triangles
+        pos, matid, mats = sy.pos, sy.matid, sy.materials
+        kw = dict(fov=0.6, width=480, height=270, spt=3, render_type="phong", shading="flat", aspect_mode=1, max_depth=4, **CAMERAS["original"])
+    else:
+        n_tri = 400
+        rs = np.random.RandomState(31)
+        centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+        size = np.exp(rs.uniform(np.log(0.05), np.log(3.0), (n_tri, 1, 1)))
+        pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+        mats = scenes["sphere"].materials.copy()
+        emissive = [m for m in range(mats.shape[0]) if np.any(mats[m, 12:15] != 0)]
+        plain = [m for m in range(mats.shape[0]) if m not in emissive]
+        if case == "soup_odd_materials":  # (a material is 18 floats: diffuse 3:6, specular 6:9, emission 12:15, shininess 15)
+            mats[plain[0], 15] = -2.0
+            mats[plain[1], 3] = np.inf
+            mats[plain[2], 7] = np.nan
+            mats[plain[3], 15] = 3e7
+        if case == "soup_huge_light":
+            mats[emissive[0], 12:15] = 3e35
+        matid = np.asarray(plain, np.int32)[rs.randint(0, len(plain), n_tri)]
+        matid[[3, n_tri // 2, n_tri - 5]] = emissive[0]
+        mb, md = 8, 4
+        kw = dict(fov=0.9, width=160, height=120, spt=4, render_type="blinn_phong" if "blinn" in case else "phong", shading="flat", max_depth=3,
+                  cam_pos=[0.5, 0.3, -14.0], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=40.0, cull="two_sided" not in case)
+    cfg = rt.make_render_config(**kw)
+    frames = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("RT_SKIP_UNLIT", skip)
+        g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+        g.Build(pos)
+        g.set_shading(nrm, matid, mats)
+        img, st = g.render(cfg)
+        frames[skip] = (img, (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays, st.levels), st.shadow_rays_not_traced)
+        g.close()
+    monkeypatch.delenv("RT_SKIP_UNLIT")
+    assert np.array_equal(bits(frames["1"][0]), bits(frames["0"][0]))
+    assert frames["1"][1] == frames["0"][1] and frames["1"][1][3] > 10000
+    # the rule is at work where it may be, and only there
+    assert frames["0"][2] == 0
+    if case in ("sphere_smooth", "soup_huge_light"):
+        assert frames["1"][2] == 0
+    else:
+        assert 0.02 * frames["1"][1][3] < frames["1"][2] < frames["1"][1][3], (frames["1"][2], frames["1"][1][3])
+    if case in ("original_phong", "soup_phong") and walk == "lane":  # ... and the oracle's frame, which knows no such rule
+        osc = orc.Scene.from_arrays(pos, nrm, matid, mats)
+        okw = dict(kw, aspect_mode=orc.ASPECT_TRUE) if kw.get("aspect_mode") else kw
+        ref, _, _, ost = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, **okw), want_hits=False)
+        assert np.abs(frames["1"][0] - ref).max() <= 1.0 / 255.0
+        assert frames["1"][1][0] == ost.search_calls
 
 
 @pytest.mark.parametrize("factor", [1.02, 1.5, 4.0, 64.0])

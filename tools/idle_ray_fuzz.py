@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Randomised check of the rule that leaves out shadow rays whose answer cannot change the image (GPU box): N random
+triangle soups with random material tables (zero and non-zero specular colours, reflecting materials, now and then an
+infinite or NaN colour, a negative or huge shininess, a light whose emission overflows a product), random lights,
+octree parameters, cameras, light-sample counts, one- and two-sided triangle tests, with the per-lane or the task-pool
+walks forced or the library's own choice of form; every frame is rendered with the rule and with RT_SKIP_UNLIT=0, which
+traces every ray, and must be the same bit for bit with the same ray counts.
+usage: idle_ray_fuzz.py [N=200] [first seed=1000] [first case=0]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+rays_total = shadow_total = 0
+walks = {"lane": 0, "pool": 0, "auto": 0}
+odd = 0
+bad = []
+skipped = []
+for case in range(first_case, n_cases):
+    print(f"case {case}", file=sys.stderr, flush=True)
+    rs = np.random.RandomState(seed0 + case)
+    kind = case % 3
+    n_tri, mb, md = [(int(rs.randint(20, 400)), int(rs.choice([4, 16])), int(rs.randint(1, 4))),
+                     (int(rs.randint(300, 2500)), int(rs.choice([4, 8, 16])), int(rs.randint(3, 6))),
+                     (int(rs.randint(20000, 60000)), 16, 10)][kind]
+    centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+    lo, hi = (0.05, 3.0) if kind < 2 else (0.02, 0.4)
+    size = np.exp(rs.uniform(np.log(lo), np.log(hi), (n_tri, 1, 1)))
+    pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+    # a material is 18 floats: diffuse 3:6, specular 6:9, transmittance 9:12, emission 12:15, shininess 15, index of refraction 16
+    n_mat = 6
+    mats = np.zeros((n_mat, 18), np.float32)
+    mats[:, 3:6] = rs.rand(n_mat, 3)
+    for m in range(n_mat):
+        if rs.rand() < 0.5:
+            mats[m, 6:9] = rs.rand(3) * (rs.rand(3) < 0.8)
+    mats[:, 15] = rs.choice([0.0, 1.0, 10.0, 200.0], n_mat)
+    mats[:, 16] = 1.5
+    mats[0, 12:15] = rs.uniform(1.0, 40.0, 3)  # the emissive material
+    if case % 4 == 1:
+        mats[0, 6:9] = 0.0  # (a light that reflects nothing)
+    if case % 7 == 0:  # values the rule must keep away from
+        odd += 1
+        m = int(rs.randint(1, n_mat))
+        what = int(rs.randint(0, 5))
+        if what == 0:
+            mats[m, 15] = -3.0
+        elif what == 1:
+            mats[m, 3 + int(rs.randint(0, 3))] = np.inf
+        elif what == 2:
+            mats[m, 6 + int(rs.randint(0, 3))] = np.nan
+        elif what == 3:
+            mats[m, 15] = 1e8
+        else:
+            mats[0, 12:15] = 3e35
+    matid = rs.randint(1, n_mat, n_tri).astype(np.int32)
+    n_lights = int(rs.randint(1, 7))
+    matid[rs.choice(n_tri, n_lights, replace=False)] = 0
+    cam_pos = (rs.rand(3) * 4.0 - 2.0 + np.array([0.0, 0.0, -13.0])).astype(np.float32)
+    kw = dict(fov=float(rs.uniform(0.5, 1.0)), width=64, height=48, spt=int(rs.choice([1, 3, 8, 33])), render_type=str(rs.choice(["phong", "blinn_phong"])),
+              shading="flat", max_depth=int(rs.randint(0, 4)), cam_pos=[float(x) for x in cam_pos], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0],
+              max_distance=40.0, aspect_mode=1, seed=int(rs.randint(1, 1 << 30)), cull=bool(case % 5 != 3))
+    cfg = rt.make_render_config(**kw)
+    walk = ["lane", "pool", "auto"][(case // 3) % 3]
+    walks[walk] += 1
+    for k in ("RT_TRAVERSAL", "RT_DISABLE_SMALL_TREE"):
+        os.environ.pop(k, None)
+    if walk != "auto":
+        os.environ.update({"RT_TRAVERSAL": walk, "RT_DISABLE_SMALL_TREE": "1"})
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["RT_SKIP_UNLIT"] = flag
+        g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+        try:
+            g.Build(pos)
+        except RuntimeError:  # (a soup on which Octree::Build's own invariant fails, octree.cc:124-152: the reference exits there)
+            skipped.append(seed0 + case)
+            g.close()
+            break
+        g.set_shading(None, matid, mats)
+        img, st = g.render(cfg)
+        out[flag] = (img, (st.rays, st.secondary_rays, st.shadow_rays))
+        g.close()
+    if len(out) < 2:
+        continue
+    rays_total += out["1"][1][0]
+    shadow_total += out["1"][1][2]
+    if not (np.array_equal(out["1"][0].view(np.uint32), out["0"][0].view(np.uint32)) and out["1"][1] == out["0"][1]):
+        bad.append(seed0 + case)
+        print(f"seed {seed0 + case}: frames differ", flush=True)
+    if case % 20 == 19:
+        print(f"{case + 1} cases, {len(bad)} differ", flush=True)
+print(f"idle_ray_fuzz: {n_cases} scenes (walks {walks}, {odd} with values the rule must keep away from), {rays_total} rays of which {shadow_total} shadow rays; "
+      f"frames that differ from those with every ray traced: {len(bad)} {bad}; scenes the octree build rejects: {len(skipped)}")
+sys.exit(1 if bad else 0)
