@@ -3,7 +3,8 @@
 triangle soups with random material tables (zero and non-zero specular colours, reflecting materials, now and then an
 infinite or NaN colour, a negative or huge shininess, a light whose emission overflows a product), random lights,
 octree parameters, cameras, light-sample counts, one- and two-sided triangle tests, with the per-lane or the task-pool
-walks forced or the library's own choice of form; every frame is rendered with the rule and with RT_SKIP_UNLIT=0, which
+walks forced or the library's own choice of form, and the ways lights with forms of their own are served in rotation;
+every frame is rendered with the rule and with RT_SKIP_UNLIT=0, which
 traces every ray, and must be the same bit for bit with the same ray counts.
 usage: idle_ray_fuzz.py [N=200] [first seed=1000] [first case=0]"""
 import os
@@ -69,10 +70,12 @@ for case in range(first_case, n_cases):
     cfg = rt.make_render_config(**kw)
     walk = ["lane", "pool", "auto"][(case // 3) % 3]
     walks[walk] += 1
-    for k in ("RT_TRAVERSAL", "RT_DISABLE_SMALL_TREE"):
+    for k in ("RT_TRAVERSAL", "RT_DISABLE_SMALL_TREE", "RT_LANE_SIDE_MAX_RAYS", "RT_LIGHT_MERGE"):
         os.environ.pop(k, None)
     if walk != "auto":
         os.environ.update({"RT_TRAVERSAL": walk, "RT_DISABLE_SMALL_TREE": "1"})
+    # how lights with forms of their own are served, in rotation: the library's choice, one light per pass, never merged
+    os.environ.update([{}, {"RT_LANE_SIDE_MAX_RAYS": "0"}, {"RT_LIGHT_MERGE": "0"}, {"RT_LIGHT_MERGE": "0", "RT_LANE_SIDE_MAX_RAYS": "0"}][(case // 9) % 4])
     out = {}
     for flag in ("1", "0"):
         os.environ["RT_SKIP_UNLIT"] = flag
