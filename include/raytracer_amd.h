@@ -223,8 +223,8 @@ typedef struct rt_render_stats {
     /* Shadow rays (counted in shadow_rays, as the reference casts them) that were answered without a walk: the light
      * sample they test adds a zero to the hit's colour whether it is visible or not -- the light faces away from the
      * hit, or the surface faces away from the light and has no specular colour -- so it is reported as shadowed and the
-     * image has the same bits.  Flat shading, finite lights and materials, big trees (per-lane walks) only;
-     * RT_SKIP_UNLIT=0 at rt_ads_create traces every ray. */
+     * image has the same bits (the second case with flat shading only).  Finite lights and materials, big trees
+     * (per-lane walks) only; RT_SKIP_UNLIT=0 at rt_ads_create traces every ray. */
     uint64_t shadow_rays_not_traced;
 } rt_render_stats;
 

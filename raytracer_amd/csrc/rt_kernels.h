@@ -561,18 +561,19 @@ __device__ __forceinline__ f3 light_sample(const LightDev& L, uint32_t pre, uint
 //      are zeros (Phong's specular term has no such factor, hence the condition on the colour).
 // "Zero times x is zero" needs x finite: the host sets the bits only for scenes whose lights and materials are finite
 // and moderate (rt_scene_set_shading), the shininess in [0, 1e6] (a finite power), and here the ray must have a finite
-// length.  N is the face normal: flat shading only.  Both tests use the very expressions of the shading code, so a
-// sample is skipped exactly when that code would multiply by its zero.  On a closed mesh the skipped rays are the
+// length.  N is the face normal, so rule B is for flat shading only; rule A also holds with smooth shading, whose
+// interpolated normal is a normalised vector -- components of magnitude <= 1 or NaN, and max(0, NaN) is 0.  Both tests
+// use the very expressions of the shading code, so a sample is skipped exactly when that code would multiply by its zero.  On a closed mesh the skipped rays are the
 // expensive ones: with back faces culled a ray that starts on the far side of a sphere runs through its whole interior.
 constexpr uint32_t kDarkFinite = 1u;        // rule A may be used (and rule B with kDarkSpecZero)
 constexpr uint32_t kDarkEmissionZero = 2u;  // the material's emission is zero: needed with Phong
 constexpr uint32_t kDarkSpecZero = 4u;      // the material's specular colour is zero
 __device__ __forceinline__ bool shadow_ray_idle(const FrameParams& F, uint32_t dark, f3 N, f3 n_l, f3 d_l, float dist) {
-    if (!(dark & kDarkFinite) || F.shading_type != 0) return false;
+    if (!(dark & kDarkFinite)) return false;
     if (F.render_type == 2 && !(dark & kDarkEmissionZero)) return false;
     if (!(dist < RT_INF)) return false;
     const bool light_faces_away = !(0.0f < dot(n_l, -d_l));
-    const bool surface_faces_away = !(0.0f < dot(N, d_l)) && (dark & kDarkSpecZero) != 0u;
+    const bool surface_faces_away = F.shading_type == 0 && !(0.0f < dot(N, d_l)) && (dark & kDarkSpecZero) != 0u;
     return light_faces_away || surface_faces_away;
 }
 
@@ -610,7 +611,8 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
     valid = valid && active;
     // Rays that need no answer (shadow_ray_idle) are left out where every lane walks its own ray: the lanes they free
     // take over other rays' subtrees or tasks, and waves without a ray end at once.  A wave that walks its rays together
-    // only gains if all 64 are left out, which does not pay for the test.
+    // only gains if all 64 are left out, which does not pay for the test (configs with the reference's integer aspect
+    // ratio, whose rays all lie in one horizontal plane, have no such hits at all).
     constexpr bool kSkipIdle = MODE == MODE_LANE || MODE == MODE_POOL;
     float t = 0.0f;
     uint32_t tri = 0;

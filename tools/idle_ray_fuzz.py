@@ -2,7 +2,7 @@
 """Randomised check of the rule that leaves out shadow rays whose answer cannot change the image (GPU box): N random
 triangle soups with random material tables (zero and non-zero specular colours, reflecting materials, now and then an
 infinite or NaN colour, a negative or huge shininess, a light whose emission overflows a product), random lights,
-octree parameters, cameras, light-sample counts, one- and two-sided triangle tests, with the per-lane or the task-pool
+octree parameters, cameras, light-sample counts, one- and two-sided triangle tests, flat and smooth shading, with the per-lane or the task-pool
 walks forced or the library's own choice of form, and the ways lights with forms of their own are served in rotation;
 every frame is rendered with the rule and with RT_SKIP_UNLIT=0, which
 traces every ray, and must be the same bit for bit with the same ray counts.
@@ -63,9 +63,24 @@ for case in range(first_case, n_cases):
     matid = rs.randint(1, n_mat, n_tri).astype(np.int32)
     n_lights = int(rs.randint(1, 7))
     matid[rs.choice(n_tri, n_lights, replace=False)] = 0
+    # every fourth scene with smooth shading: vertex normals scattered around the face normal, now and then vertex normals
+    # that cancel or vanish (an interpolated normal that is NaN)
+    nrm = None
+    if case % 4 == 2:
+        fn = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
+        fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-30)
+        nrm = fn[:, None, :] + rs.randn(n_tri, 3, 3) * 0.4
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=2, keepdims=True), 1e-30)
+        if case % 8 == 2:
+            k = rs.choice(n_tri, max(n_tri // 20, 1), replace=False)
+            nrm[k] = 0.0
+            k = rs.choice(n_tri, max(n_tri // 20, 1), replace=False)
+            nrm[k, 1] = -nrm[k, 0]
+            nrm[k, 2] = 0.0
+        nrm = nrm.astype(np.float32)
     cam_pos = (rs.rand(3) * 4.0 - 2.0 + np.array([0.0, 0.0, -13.0])).astype(np.float32)
     kw = dict(fov=float(rs.uniform(0.5, 1.0)), width=64, height=48, spt=int(rs.choice([1, 3, 8, 33])), render_type=str(rs.choice(["phong", "blinn_phong"])),
-              shading="flat", max_depth=int(rs.randint(0, 4)), cam_pos=[float(x) for x in cam_pos], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0],
+              shading="flat" if nrm is None else "smooth", max_depth=int(rs.randint(0, 4)), cam_pos=[float(x) for x in cam_pos], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0],
               max_distance=40.0, aspect_mode=1, seed=int(rs.randint(1, 1 << 30)), cull=bool(case % 5 != 3))
     cfg = rt.make_render_config(**kw)
     walk = ["lane", "pool", "auto"][(case // 3) % 3]
@@ -86,7 +101,7 @@ for case in range(first_case, n_cases):
             skipped.append(seed0 + case)
             g.close()
             break
-        g.set_shading(None, matid, mats)
+        g.set_shading(nrm, matid, mats)
         img, st = g.render(cfg)
         out[flag] = (img, (st.rays, st.secondary_rays, st.shadow_rays))
         g.close()
