@@ -257,6 +257,10 @@ def memory_side(kernels, name, workload):
         kernels[k]["beyond_l2_GBps"] = gbps
         kernels[k]["hbm_frac"] = gbps / HBM_PEAK_GBPS
         kernels[k]["l2_hit_rate"] = e.get("l2_hit_rate")
+        if e.get("valu_lane_ops_per_launch"):
+            # executed wave64 VALU lane-ops (counted, per-launch mean) over this run's kernel time and the no-FMA issue peak
+            kernels[k]["valu_issue_frac"] = e["valu_lane_ops_per_launch"] / (kernels[k]["avg_launch_ms"] * 1e-3) / 1e12 / FP32_NO_FMA_PEAK_TOPS
+            kernels[k]["lanes_active_per_valu_inst"] = e.get("lanes_active")
         kernels[k]["counters_source"] = src
 
 
