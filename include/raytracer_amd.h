@@ -256,6 +256,16 @@ int rt_ads_set_render_streams(rt_ads* ads, int n);
  * the (light, triangle) pairs of the scene and how many of them are left out. */
 int rt_ads_light_forms(const rt_ads* ads, uint32_t* lights_with_forms, uint64_t* pairs, uint64_t* pairs_left_out);
 
+/* No counterpart in the reference: inspection of a second set of lists of the small-tree form.  A shadow ray starts on
+ * the triangle its hit lies on; with back-face culling on, a triangle that has ALL of that hit triangle behind its plane
+ * (by a rounding margin) cannot be an accepted occluder of the ray either -- running against the normal it moves away
+ * from the plane, running with it it meets a back face.  rt_scene_set_shading builds, per light and hit triangle, the
+ * light's list without those triangles, and a wavefront of rt_render whose hits lie on one triangle walks that list
+ * (frames whose camera is within 4 scene diagonals of the scene only); same visibility bits as Renderer::is_shadowed
+ * (renderer.cc:288-313).  RT_HIT_CULL=0 in the environment at rt_ads_create switches it off.  Reports the (hit triangle,
+ * listed triangle) pairs of those lists and how many of them are left out; zeros: no such lists. */
+int rt_ads_hit_lists(const rt_ads* ads, uint64_t* pairs, uint64_t* pairs_left_out);
+
 /* Frames in flight.  rt_render returns when its frame is complete, so a caller that renders a sequence of frames (or,
  * with several GPUs, its bands of each) leaves the GPU to one frame at a time -- and a short frame is a chain of
  * launches that each last as long as their slowest wavefront.  rt_render_submit queues a frame and returns at once with a

@@ -69,7 +69,7 @@ class RenderStats(C.Structure):
 
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
-    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_forms", "rt_ads_light_forms", "rt_ads_tree_stats",
+    "rt_ads_kind_from_name", "rt_ads_create", "rt_ads_destroy", "rt_ads_build", "rt_ads_export_tree", "rt_ads_tree_forms", "rt_ads_light_forms", "rt_ads_hit_lists", "rt_ads_tree_stats",
     "rt_ads_query_stats", "rt_ads_reset_query_stats", "rt_ads_collect_search_stats", "rt_ads_search", "rt_ads_search_noalloc", "rt_ads_trace_closest", "rt_ads_trace_any",
     "rt_scene_set_shading", "rt_render", "rt_render_submit", "rt_render_wait", "rt_ads_set_render_streams", "rt_render_primary_hits", "rt_rng_u31", "rt_last_error", "rt_version",
     "rt_host_tree_build", "rt_host_tree_destroy", "rt_host_tree_sizes", "rt_host_tree_export",
@@ -105,6 +105,7 @@ def lib():
     L.rt_ads_export_tree.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_ads_tree_forms.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.rt_ads_light_forms.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rt_ads_hit_lists.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rt_ads_tree_stats.argtypes = [vp, C.POINTER(TreeStats)]
     L.rt_ads_query_stats.argtypes = [vp, C.POINTER(QueryStats)]
     L.rt_ads_reset_query_stats.argtypes = [vp]

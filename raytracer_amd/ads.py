@@ -220,6 +220,13 @@ class GpuOctree(Ads):
         _capi.check(_capi.lib().rt_ads_light_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def hit_lists(self):
+        """((hit triangle, listed triangle) pairs of the per-hit-triangle lists of the small-tree form, pairs left out
+        because the listed triangle has all of the hit triangle behind it); zeros = not in use."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _capi.check(_capi.lib().rt_ads_hit_lists(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def tree_stats(self):
         st = _capi.TreeStats()
         _capi.check(_capi.lib().rt_ads_tree_stats(self._h, C.byref(st)))

@@ -347,6 +347,10 @@ struct rt_ads {
     std::vector<NodeRec> h_cl_nodes;
     bool light_cull = true;  // RT_LIGHT_CULL=0 at creation: every light's any-hit passes walk the full lists
     bool skip_unlit = true;  // RT_SKIP_UNLIT=0 at creation: shadow rays whose answer cannot change the image are traced too
+    bool hit_cull = true;    // RT_HIT_CULL=0 at creation: no per-(light, hit triangle) lists in the small-tree form
+    uint64_t hit_pairs = 0, hit_pairs_culled = 0;  // (hit triangle, listed triangle) pairs of those lists, and the ones left out
+    double scene_mid[3] = {0, 0, 0}, scene_diag = 0;  // the scene's box, for the camera check of the hit lists
+    DevBuf<uint2> d_hit_lists;
     DevBuf<LightForm> d_light_forms;
     DevBuf<LeafTri> d_light_flat, d_light_cl_tris;
     DevBuf<NodeRec> d_light_cl_nodes;
@@ -699,6 +703,7 @@ int rt_ads_create(const rt_ads_config* cfg, rt_ads** out) {
     a->builder = (int)cfg->builder;
     if (const char* e = getenv("RT_LIGHT_CULL")) a->light_cull = !(e[0] == '0');
     if (const char* e = getenv("RT_SKIP_UNLIT")) a->skip_unlit = !(e[0] == '0');
+    if (const char* e = getenv("RT_HIT_CULL")) a->hit_cull = !(e[0] == '0');
     if (const char* e = getenv("RT_LIGHT_MERGE")) a->light_merge = !(e[0] == '0');
     if (const char* e = getenv("RT_LANE_SIDE_MAX_RAYS")) a->lane_side_max_rays = (uint64_t)atoll(e);
     if (const char* e = getenv("RT_RENDER_STREAMS")) a->render_streams = std::min(std::max(atoi(e), 1), kMaxRenderStreams);
@@ -854,6 +859,8 @@ constexpr uint32_t kMaxLightForms = 64, kMaxLaneLightForms = 8;
 int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     a->light_forms_ready = a->light_forms_lane = a->lights_merged = false;
     a->light_pairs = a->light_pairs_culled = 0;
+    a->hit_pairs = a->hit_pairs_culled = 0;
+    a->scene_diag = 0.0;
     if (!a->light_cull) return RT_OK;
     const size_t nl = light_tri.size();
     const bool have_flat = !a->h_flat_tris.empty(), have_cl = !a->h_cl_nodes.empty();
@@ -962,13 +969,82 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
             do all.push_back(zero); while ((all.size() - first[l]) % kTriChunk != 0);  // (at least one record: a count of 0 means "no small-tree form")
             count[l] = (uint32_t)(all.size() - first[l]);
         }
+        // Per (light, hit triangle h): the light's list without the triangles j that have ALL of h behind their plane.
+        // A shadow ray that starts on h starts behind such a plane: running against N_j it moves away from the plane and
+        // its crossing lies at t < 0, running with N_j it meets a back face -- never an accepted occluder, by the same
+        // argument and the same margin m_j as above with the hit point in the light's place.  The hit point is not
+        // exactly on h: the reference's t of the hit is off by at most 4 * 2^-24 * (k_h (|q| + t) + t), and |q| + t stays
+        // below 10 D for a camera within 4 D of the scene (render_bands checks that per frame), so h must lie behind
+        // the plane by m_j + m_hit(h), m_hit(h) = 64 * 2^-24 * (10 k_h + 5) * D -- sixteen times that bound again.
+        // A wave whose hits lie on one triangle walks that triangle's list (k_shadow).
+        std::vector<uint2> hit_lists;
+        a->hit_pairs = a->hit_pairs_culled = 0;
+        if (a->hit_cull && n >= 2 && n <= kFlatMaxTris && (uint64_t)nb * n * (a->h_flat_tris.size() + kTriChunk) <= (1ull << 21)) {
+            struct Plane { double N[3], nn, m, m_hit; bool ok; };
+            std::vector<Plane> pl(n);
+            for (uint64_t j = 0; j < n; ++j) {
+                const float* p = a->positions.data() + j * 9;
+                double e1[3], e2[3];
+                for (int k = 0; k < 3; ++k) {
+                    e1[k] = (double)(float)(p[3 + k] - p[k]);
+                    e2[k] = (double)(float)(p[6 + k] - p[k]);
+                }
+                Plane& P = pl[j];
+                P.N[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                P.N[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                P.N[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                P.nn = std::sqrt(P.N[0] * P.N[0] + P.N[1] * P.N[1] + P.N[2] * P.N[2]);
+                const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                const double kappa = l1 * l2 / P.nn;
+                P.m = margin_scale * 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
+                P.m_hit = margin_scale * 64.0 * std::ldexp(1.0, -24) * (10.0 * kappa + 5.0) * D;
+                P.ok = P.nn > 0.0 && std::isfinite(P.nn) && std::isfinite(P.m) && std::isfinite(P.m_hit);
+            }
+            std::vector<uint8_t> behind(n * n, 0);  // behind[h * n + j]: all of triangle h lies behind the plane of j
+            for (uint64_t h = 0; h < n; ++h) {
+                if (!pl[h].ok) continue;
+                const float* q = a->positions.data() + h * 9;
+                for (uint64_t j = 0; j < n; ++j) {
+                    if (j == h || !pl[j].ok) continue;
+                    const float* p = a->positions.data() + j * 9;
+                    bool all_behind = true;
+                    for (int v = 0; v < 3 && all_behind; ++v) {
+                        double side = 0.0;
+                        for (int k = 0; k < 3; ++k) side += pl[j].N[k] * ((double)q[v * 3 + k] - (double)p[k]);
+                        all_behind = side / pl[j].nn <= -(pl[j].m + pl[h].m_hit);
+                    }
+                    behind[h * n + j] = all_behind ? 1 : 0;
+                }
+            }
+            hit_lists.resize(nb * n);
+            for (size_t l = 0; l < nb; ++l)
+                for (uint64_t h = 0; h < n; ++h) {
+                    const size_t begin = all.size();
+                    for (const LeafTri& t : a->h_flat_tris) {
+                        if (culled[l * n + t.tri]) continue;
+                        ++a->hit_pairs;
+                        if (behind[h * n + t.tri]) ++a->hit_pairs_culled;
+                        else all.push_back(t);
+                    }
+                    do all.push_back(zero); while ((all.size() - begin) % kTriChunk != 0);
+                    hit_lists[l * n + h] = make_uint2((uint32_t)(begin - first[l]), (uint32_t)(all.size() - begin));
+                }
+        }
         for (int k = 0; k < kTriChunk; ++k) all.push_back(zero);  // the pass reads whole blocks
         HIP_TRY(a->d_light_flat.reserve(all.size()));
         HIP_TRY(hipMemcpy(a->d_light_flat.p, all.data(), all.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+        if (!hit_lists.empty()) {
+            HIP_TRY(a->d_hit_lists.reserve(hit_lists.size()));
+            HIP_TRY(hipMemcpy(a->d_hit_lists.p, hit_lists.data(), hit_lists.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        }
         for (size_t l = 0; l < nb; ++l) {
             forms[l].flat_tris = a->d_light_flat.p + first[l];
             forms[l].n_flat_tris = count[l];
+            forms[l].hit_lists = hit_lists.empty() ? nullptr : a->d_hit_lists.p + l * n;
         }
+        // the frames whose camera is near enough for the hit lists' margin: within 4 D of the middle of the scene's box
+        for (int k = 0; k < 3; ++k) a->scene_mid[k] = 0.5 * (lo[k] + hi[k]);
+        a->scene_diag = D;
     }
     if (have_cl) {  // per light: every cluster's list without the culled triangles, and node records that point at them
         const size_t n_rec = a->h_cl_nodes.size();
@@ -1371,6 +1447,15 @@ int rt_ads_light_forms(const rt_ads* a, uint32_t* lights_with_forms, uint64_t* p
     if (lights_with_forms) *lights_with_forms = on ? a->n_lights : 0u;
     if (pairs) *pairs = on ? a->light_pairs : 0u;
     if (pairs_left_out) *pairs_left_out = on ? a->light_pairs_culled : 0u;
+    return RT_OK;
+}
+
+int rt_ads_hit_lists(const rt_ads* a, uint64_t* pairs, uint64_t* pairs_left_out) {
+    if (!a) return fail(RT_ERR_INVALID, "null argument");
+    if (!a->shading_set) return fail(RT_ERR_NOT_BUILT, "rt_scene_set_shading has not been called");
+    const bool on = a->light_cull && a->light_forms_ready && a->hit_cull;
+    if (pairs) *pairs = on ? a->hit_pairs : 0u;
+    if (pairs_left_out) *pairs_left_out = on ? a->hit_pairs_culled : 0u;
     return RT_OK;
 }
 
@@ -1959,6 +2044,13 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
     FrameParams F;
     uint32_t n0 = 0;
     if (int rc = frame_params(a, c, F, n0)) return rc;
+    // the per-(light, hit triangle) lists of the small-tree form assume a camera within 4 D of the scene (make_light_forms)
+    bool hit_lists_ok = false;
+    if (a->scene_diag > 0.0) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) d2 += ((double)c->cam_pos[k] - a->scene_mid[k]) * ((double)c->cam_pos[k] - a->scene_mid[k]);
+        hit_lists_ok = d2 <= 16.0 * a->scene_diag * a->scene_diag;  // (false for a NaN)
+    }
     if (int rc = ensure_events(x)) return rc;
     const SceneDev S = scene_dev(a);
     const uint32_t max_levels = (uint32_t)c->max_depth + 1;
@@ -2100,7 +2192,7 @@ int render_bands(rt_ads* a, FrameCtx& x, const rt_render_config* c, float* d_out
                 const uint32_t sparse_a = pool_sparse(a, mode_a, (uint64_t)n_hits << gshift, 1u << gshift);
                 const dim3 grid_a((uint32_t)((mode_threads(mode_a, (uint64_t)n_hits << gshift, sparse_a) + block_a.x - 1) / block_a.x));
                 launch_shadow(F.cull != 0, mode_a, a->fast_tri, light_trees && gshift > pshift, grid_a, block_a, lane_lds(a, mode_a, block_a.x, false), stream, S, F, L, lv.rays.p, cap,
-                              lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words, pshift, gshift, cnt, launch_opts(a, sparse_a));
+                              lv.hit_t.p, lv.hit_tri.p, lv.work.p, lv.vis.p, words, pshift, gshift, cnt, launch_opts(a, sparse_a) | (hit_lists_ok ? kOptHitLists : 0u));
                 HIP_TRY(hipGetLastError());
                 st.launches_shadow++;
                 if (a->collect_stats) {

@@ -66,6 +66,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t rt_dyn_lds[];  // (64-bi
 // their scalar register budget): bits 0..3 `sparse` (see ray_index), bit 4 `clip` (walk only the part of a ray that can
 // contribute a result, see Span), bits 8..15 the tree's levels of internal nodes (depth of the per-lane stacks).
 __host__ __device__ constexpr uint32_t trace_opts(uint32_t sparse, bool clip, uint32_t levels) { return sparse | (clip ? 16u : 0u) | (levels << 8); }
+constexpr uint32_t kOptHitLists = 32u;  // k_shadow: the frame's camera is near enough for LightForm::hit_lists
 __device__ __forceinline__ uint32_t opts_sparse(uint32_t opts) { return opts & 15u; }
 __device__ __forceinline__ bool opts_clip(uint32_t opts) { return (opts & 16u) != 0u; }
 __device__ __forceinline__ uint32_t opts_levels(uint32_t opts) { return (opts >> 8) & 0xffu; }
@@ -154,7 +155,9 @@ struct alignas(16) LightForm {
     // the same copies seen from light 0's arrays (all lights' copies lie one after the other): what a lane adds to the
     // record and slot indices of its light's copy when the lanes of a wave walk different lights' trees
     uint32_t lane_rec_base, lane_slot_base;
-    uint64_t pad;
+    // small-tree form, per hit triangle h: where (records after flat_tris) and how long the light's list is without the
+    // triangles that have all of h behind them (make_light_forms); nullptr: no such lists
+    const uint2* hit_lists;
 };
 static_assert(sizeof(LightForm) == 64, "");
 
@@ -689,6 +692,15 @@ __global__ void __launch_bounds__(WAVES * 64) RT_SHADOW_OCCUPANCY(MODE) k_shadow
                 if (MODE == MODE_WAVE && T.n_flat_tris != 0 && lf.flat_tris != nullptr) {
                     T.flat_tris = lf.flat_tris;
                     T.n_flat_tris = lf.n_flat_tris;
+                    // a wave whose hits lie on one triangle: that triangle's (shorter) list
+                    if ((opts & kOptHitLists) != 0u && lf.hit_lists != nullptr) {
+                        const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)tri, __builtin_ctzll(on_mask));
+                        if (ballot64(on && tri != h0) == 0) {
+                            const RT_CONST uint32_t* e = (const RT_CONST uint32_t*)(uintptr_t)lf.hit_lists + 2u * h0;
+                            T.flat_tris = lf.flat_tris + e[0];
+                            T.n_flat_tris = e[1];
+                        }
+                    }
                 }
                 if (MODE == MODE_CLUSTER && lf.cl_nodes != nullptr) {
                     T.cl_nodes = lf.cl_nodes;

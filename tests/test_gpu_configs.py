@@ -18,6 +18,7 @@ FORMS = {
     "pool": {"RT_DISABLE_SMALL_TREE": "1", "RT_TRAVERSAL": "pool"},
     "full_lists": {"RT_LIGHT_CULL": "0"},                                   # no per-light lists: every any-hit pass walks everything
     "every_ray": {"RT_SKIP_UNLIT": "0"},                                    # shadow rays that cannot change the image are traced too
+    "no_hit_lists": {"RT_HIT_CULL": "0"},                                   # small-tree form: the light's list whatever triangle the hits lie on
 }
 
 
@@ -33,7 +34,7 @@ def bits(a):
 
 def build(rt, sc, monkeypatch=None, form="auto", builder="auto"):
     if monkeypatch is not None:
-        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_LIGHT_CULL", "RT_SKIP_UNLIT"):
+        for k in ("RT_DISABLE_SMALL_TREE", "RT_TRAVERSAL", "RT_DISABLE_CLUSTERS", "RT_LIGHT_CULL", "RT_SKIP_UNLIT", "RT_HIT_CULL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in FORMS[form].items():
             monkeypatch.setenv(k, v)
@@ -72,12 +73,12 @@ def test_original_spp64_spt32_full_size_properties(rt, orc, scenes, monkeypatch)
     sc = scenes["original"]
     kw = dict(fov=0.6, width=3840, height=2160, spp=64, spt=32, render_type="blinn_phong", shading="flat", **CAMERAS["original"])
     out = {}
-    for form in ("auto", "general", "full_lists", "every_ray"):
+    for form in ("auto", "general", "full_lists", "every_ray", "no_hit_lists"):
         g = build(rt, sc, monkeypatch, form)
         img = np.zeros((2160, 3840, 3), np.float32)
         _, st = g.render(rt.make_render_config(band_rank=3, band_world=8, **kw), out=img)
         out[form] = (img, st.rays, st.shadow_rays)
-    for form in ("general", "full_lists", "every_ray"):
+    for form in ("general", "full_lists", "every_ray", "no_hit_lists"):
         assert np.array_equal(bits(out["auto"][0]), bits(out[form][0])) and out["auto"][1:] == out[form][1:], form
     img = out["auto"][0]
     # band 3 = rows 24..31 belong to rank 3 of 8; rows 0..23 do not and must be untouched
@@ -390,6 +391,127 @@ def test_per_light_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, 
     else:
         ref, _, _, _ = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, rows=rows, **okw), want_hits=False)
         assert np.abs(frames["1"][0][rows[0]:rows[1]] - ref[rows[0]:rows[1]]).max() <= 1.0 / 255.0
+
+
+@pytest.mark.parametrize("case", ["original", "original_integer_aspect", "sphere", "soup", "soup_layers", "soup_two_sided", "soup_far_camera", "soup_many_lights"])
+def test_hit_triangle_lists_change_no_visibility_bit(rt, orc, scenes, monkeypatch, case):
+    """Small-tree form, back-face culling on: a wave whose hits lie on one triangle h walks the light's list without the
+    triangles that have all of h behind their plane -- a ray that starts behind a plane never meets its front.  The
+    frames must be those of RT_HIT_CULL=0 bit for bit, with the same ray counts, and the oracle's within the shading
+    tolerance: on Cornell-Original with the true and the reference's integer aspect ratio, on random triangle soups
+    (also with a third of the triangles in common planes: hit triangles exactly IN the plane of others), with the
+    two-sided test (which must not use the lists), with a camera farther away than the lists' margin allows (they must
+    stay unused: same frame either way) and with more lights than get lists.  Cornell-Sphere has no small-tree form."""
+    nrm = None
+    mb, md = 16, 10
+    if case in ("original", "original_integer_aspect", "sphere"):
+        name = case.split("_")[0]
+        sc = scenes[name]
+        pos, matid, mats = sc.pos, sc.matid, sc.materials
+        kw = dict(fov=0.6, width=200, height=150, spt=6, render_type="blinn_phong", shading="flat", max_depth=3,
+                  aspect_mode=0 if case.endswith("integer_aspect") else 1, **CAMERAS[name])
+    else:
+        n_tri, mb, md = 150, 64, 1
+        rs = np.random.RandomState(41)
+        centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+        size = np.exp(rs.uniform(np.log(0.05), np.log(3.0), (n_tri, 1, 1)))
+        pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+        if case == "soup_layers":
+            pos[: n_tri // 3, :, 1] = np.round(pos[: n_tri // 3, :, 1])
+        mats = scenes["sphere"].materials
+        emissive = [m for m in range(mats.shape[0]) if np.any(mats[m, 12:15] != 0)]
+        plain = [m for m in range(mats.shape[0]) if m not in emissive]
+        matid = np.asarray(plain, np.int32)[rs.randint(0, len(plain), n_tri)]
+        matid[[3, n_tri // 2, n_tri - 5]] = emissive[0]
+        if case == "soup_many_lights":
+            matid[::2] = emissive[0]
+        z_cam = -200.0 if case == "soup_far_camera" else -14.0  # (the soup's box has a diagonal of about 30)
+        kw = dict(fov=0.1 if case == "soup_far_camera" else 0.9, width=120, height=96, spt=5, render_type="phong", shading="flat", max_depth=2,
+                  cam_pos=[0.5, 0.3, z_cam], cam_up=[0.0, 1.0, 0.0], cam_dir=[0.0, 0.0, 1.0], max_distance=400.0, cull=case != "soup_two_sided")
+        if case == "soup_many_lights":
+            kw.update(width=48, height=40, spt=2)
+    cfg = rt.make_render_config(**kw)
+    frames = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RT_HIT_CULL", flag)
+        g = rt.GpuOctree({"max_triangles_per_BB": mb, "max_depth": md})
+        g.Build(pos)
+        g.set_shading(nrm, matid, mats)
+        small, _, _ = g.tree_forms()
+        pairs, left_out = g.hit_lists()
+        if flag == "0" or case in ("sphere", "soup_many_lights"):
+            assert (pairs, left_out) == (0, 0)
+        else:
+            assert small > 0 and 0 < left_out < pairs, (pairs, left_out)
+        img, st = g.render(cfg)
+        frames[flag] = (img, (st.rays, st.primary_rays, st.secondary_rays, st.shadow_rays, st.levels))
+        g.close()
+    monkeypatch.delenv("RT_HIT_CULL")
+    assert np.array_equal(bits(frames["1"][0]), bits(frames["0"][0]))
+    assert frames["1"][1] == frames["0"][1] and frames["1"][1][3] > 10000
+    if case in ("original", "soup", "soup_layers"):
+        osc = orc.Scene.from_arrays(pos, nrm, matid, mats)
+        okw = dict(kw, aspect_mode=orc.ASPECT_TRUE) if kw.get("aspect_mode") else kw
+        ref, _, _, ost = orc.render(osc, orc.Octree(osc, mb, md), orc.make_cfg(rng_mode=orc.RNG_COUNTER, **okw), want_hits=False)
+        assert np.abs(frames["1"][0] - ref).max() <= 1.0 / 255.0
+        assert frames["1"][1][0] == ost.search_calls
+
+
+@pytest.mark.parametrize("factor", [1.02, 1.5, 4.0, 64.0])
+def test_hit_triangle_lists_at_their_margin(rt, scenes, monkeypatch, factor):
+    """The worst case for the rule behind the per-hit-triangle lists: a wall whose top edge ends only `factor` times the
+    rule's margin BELOW the plane of a 20 m floor that faces up (1.9 mm for factor 1.02), lit by a light wall at the same
+    height on the other side -- the shadow rays run under the floor, almost parallel to it, where the triangle test's
+    determinant is rounding noise.  The floor is left out of the wall's lists; the frames must still be those of the
+    light's own lists, bit for bit, one- and two-sided.  (Run by hand with RT_LIGHT_CULL_MARGIN_SCALE, which shrinks the
+    margin in the library and here alike, to see how far below the margin the rule still holds.)"""
+    def quad(p0, p1, p2, p3):
+        return [[p0, p1, p2], [p0, p2, p3]]
+
+    import os
+    diag = float(np.sqrt(20.0 ** 2 + 20.0 ** 2 + 1.0 ** 2))
+    unit = 64.0 * 2.0 ** -24 * diag * float(os.environ.get("RT_LIGHT_CULL_MARGIN_SCALE", "1"))
+    margin = unit * (2.0 * 1.0 + 1.0) + unit * (10.0 * 1.0 + 5.0)  # m_j of the floor + m_hit of the wall (right triangles: k = 1)
+    g = factor * margin
+    tris = []
+    tris += quad([-10, 0, -10], [-10, 0, 10], [10, 0, 10], [10, 0, -10])      # the floor, normal +y
+    tris += quad([8, -1, -2], [8, -g, -2], [8, -g, 2], [8, -1, 2])            # the light wall, facing -x, top edge g below the floor's plane
+    tris += quad([-8, -1, -2], [-8, -1, 2], [-8, -g, 2], [-8, -g, -2])        # the wall that is looked at, facing +x
+    pos = np.asarray(tris, np.float32)
+    assert pos[4:6, :, 1].max() == np.float32(-g)
+    mats = scenes["sphere"].materials
+    emissive = next(m for m in range(mats.shape[0]) if np.any(mats[m, 12:15] != 0))
+    plain = next(m for m in range(mats.shape[0]) if not np.any(mats[m, 12:15] != 0) and not np.any(mats[m, 6:12] != 0))
+    matid = np.full(len(pos), plain, np.int32)
+    matid[2:4] = emissive
+    frames = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RT_HIT_CULL", flag)
+        a = rt.GpuOctree({"max_triangles_per_BB": 4, "max_depth": 1})  # (one subdivision: a root leaf has no lists to thin out)
+        a.Build(pos)
+        a.set_shading(None, matid, mats)
+        small, _, _ = a.tree_forms()
+        assert small > 0
+        if flag == "1":
+            pairs, left_out = a.hit_lists()
+            assert left_out >= 4  # at least the two floor triangles, for both triangles of the wall
+        imgs = []
+        # the camera looks at the wall through a keyhole: hit points within a few margins of its top edge, then within a
+        # centimetre, then the whole wall
+        for fov, cam_y in ((2.0 * np.arctan(4.0 * g / 8.0), -2.0 * g), (2.0 * np.arctan(0.01 / 8.0), -g - 0.005), (0.25, -0.5)):
+            for two_sided in (False, True):
+                cfg = rt.make_render_config(cam_pos=[0.0, float(cam_y), 0.0], cam_up=[0.0, 1.0, 0.0], cam_dir=[-1.0, 0.0, 0.0], fov=float(fov), width=96, height=96,
+                                            spt=16, render_type="blinn_phong", shading="flat", cull=not two_sided, max_distance=40.0, aspect_mode=1, max_depth=0)
+                img, st = a.render(cfg)
+                imgs.append((img, st.rays, st.shadow_rays))
+        frames[flag] = imgs
+        a.close()
+    monkeypatch.delenv("RT_HIT_CULL")
+    lit = 0
+    for k, ((x, rx, sx), (y, ry, sy)) in enumerate(zip(frames["1"], frames["0"])):
+        assert np.array_equal(bits(x), bits(y)) and (rx, sx) == (ry, sy), k
+        lit += int((x > 1e-6).any())
+    assert lit >= 3  # the light reaches the wall: a visibility bit that differed would show in the pixels
 
 
 @pytest.mark.parametrize("walk", ["lane", "pool"])
