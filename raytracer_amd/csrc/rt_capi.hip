@@ -741,6 +741,7 @@ void rt_ads_destroy(rt_ads* a) {
     a->d_mats.release(); a->d_lights.release(); a->d_flat_nodes.release(); a->d_flat_tris.release(); a->d_cl_nodes.release(); a->d_cl_tris.release(); a->d_stage.release(); a->d_io.release();
     for (auto& x : a->frame) x.release();
     a->d_light_forms.release(); a->d_light_flat.release(); a->d_light_cl_tris.release(); a->d_light_cl_nodes.release();
+    a->d_hit_lists.release();
     a->d_light_lane_nodes.release(); a->d_light_lane_geom.release();
     a->search.release();
     a->d_qstats.release();
