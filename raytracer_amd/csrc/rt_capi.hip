@@ -980,6 +980,7 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
         // A wave whose hits lie on one triangle walks that triangle's list (k_shadow).
         std::vector<uint2> hit_lists;
         a->hit_pairs = a->hit_pairs_culled = 0;
+        // (at most 2^21 list records, 96 MB: a list per light form and triangle, each as long as the light's own at most)
         if (a->hit_cull && n >= 2 && n <= kFlatMaxTris && (uint64_t)nb * n * (a->h_flat_tris.size() + kTriChunk) <= (1ull << 21)) {
             struct Plane { double N[3], nn, m, m_hit; bool ok; };
             std::vector<Plane> pl(n);
