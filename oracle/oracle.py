@@ -194,7 +194,10 @@ class Octree:
         o, d = _f32(orig), _f32(direction)
         buf = np.zeros(cap, np.uint32)
         n = int(lib().orc_search(self.h, _p(o), _p(d), _p(buf), cap, C.byref(stats) if stats is not None else None))
-        return buf[:min(n, cap)].copy()
+        if n > cap:  # (a ray with NaN components passes every box: its list is every leaf's list) -- once more with room for all
+            buf = np.zeros(n, np.uint32)
+            n = int(lib().orc_search(self.h, _p(o), _p(d), _p(buf), n, None))
+        return buf[:n].copy()
 
     def trace_closest(self, orig, direction, cull=True, stats=None):
         o, d = _f32(orig).reshape(-1, 3), _f32(direction).reshape(-1, 3)
