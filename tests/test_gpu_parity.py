@@ -453,6 +453,30 @@ def test_search_candidate_lists(rt, orc, scenes, scene, mb, md):
     assert np.array_equal(one, ot.search(o[0], d[0]))
 
 
+def test_search_of_a_nan_ray_lists_every_leaf_reference(rt, orc, scenes):
+    """A ray with NaN components passes every slab test (std::max / std::min keep their first argument,
+    collision_detection.h:82-83), so Search returns the list of every leaf: millions of candidates for one ray on a soup
+    of large triangles -- more than the oracle wrapper's default buffer and than one region of the device's batched
+    search.  Element for element the oracle's list, alone and inside a batch."""
+    rs = np.random.RandomState(77)
+    n_tri = 9000
+    centre = rs.rand(n_tri, 1, 3) * 10.0 - 5.0
+    size = np.exp(rs.uniform(np.log(0.03), np.log(4.0), (n_tri, 1, 1)))
+    pos = (centre + rs.randn(n_tri, 3, 3) * size).astype(np.float32)
+    sc = orc.Scene.from_arrays(pos, None, np.zeros(n_tri, np.int32), scenes["sphere"].materials)
+    g = build(rt, sc, 4, 8)
+    ot = orc.Octree(sc, 4, 8)
+    o, d = random_rays(sc, 9, 3)
+    o[4, 1] = np.nan
+    d[4, 2] = np.nan
+    ref = ot.search(o[4], d[4])
+    assert len(ref) == g.tree_stats()["leaf_refs"] > (1 << 20)
+    got = g.search_batch(np.concatenate([o, d], axis=1))
+    for i in range(o.shape[0]):
+        assert np.array_equal(got[i], ref if i == 4 else ot.search(o[i], d[i])), i
+    assert np.array_equal(g.Search(np.concatenate([o[4], d[4]])), ref)
+
+
 def test_empty_and_tiny_scenes(rt, orc, scenes):
     g = rt.GpuOctree({"max_triangles_per_BB": 16, "max_depth": 10})
     g.Build(np.zeros((0, 3, 3), np.float32))
