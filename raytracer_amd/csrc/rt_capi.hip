@@ -839,6 +839,253 @@ int make_cluster_form(rt_ads* a) {
     return RT_OK;
 }
 
+// What the builders of the per-light forms share (make_light_forms below states the rule): the handle, its triangle
+// count, the sets of forms to build, culled[l * n + j] (triangle j cannot occlude the lights of set l) and the records
+// that are filled in.
+struct LightFormJob {
+    rt_ads* a;
+    uint64_t n;
+    size_t nb;
+    const std::vector<uint8_t>& culled;
+    std::vector<LightForm>& forms;
+    double D, margin_scale;  // the diagonal of the scene's box; the test switch that shrinks the margins
+    const double* lo;        // the scene's box
+    const double* hi;
+};
+#define LIGHT_FORM_JOB_LOCALS                           \
+    rt_ads* a = J.a;                                    \
+    const uint64_t n = J.n;                             \
+    const size_t nb = J.nb;                             \
+    const std::vector<uint8_t>& culled = J.culled;      \
+    std::vector<LightForm>& forms = J.forms;            \
+    LeafTri zero;                                       \
+    memset(&zero, 0, sizeof zero)
+
+// Small-tree form, per light: the triangles in their order, padded to whole blocks with records that list no leaf; and
+// the per-hit-triangle lists.
+int flat_light_lists(const LightFormJob& J) {
+    LIGHT_FORM_JOB_LOCALS;
+    const double D = J.D, margin_scale = J.margin_scale;
+    const double* lo = J.lo;
+    const double* hi = J.hi;
+    std::vector<LeafTri> all;
+    std::vector<size_t> first(nb);
+    std::vector<uint32_t> count(nb);
+    for (size_t l = 0; l < nb; ++l) {
+        first[l] = all.size();
+        for (const LeafTri& t : a->h_flat_tris)
+            if (!culled[l * n + t.tri]) all.push_back(t);
+        do all.push_back(zero); while ((all.size() - first[l]) % kTriChunk != 0);  // (at least one record: a count of 0 means "no small-tree form")
+        count[l] = (uint32_t)(all.size() - first[l]);
+    }
+    // Per (light, hit triangle h): the light's list without the triangles j that have ALL of h behind their plane.
+    // A shadow ray that starts on h starts behind such a plane: running against N_j it moves away from the plane and
+    // its crossing lies at t < 0, running with N_j it meets a back face -- never an accepted occluder, by the same
+    // argument and the same margin m_j as above with the hit point in the light's place.  The hit point is not
+    // exactly on h: the reference's t of the hit is off by at most 4 * 2^-24 * (k_h (|q| + t) + t), and |q| + t stays
+    // below 10 D for a camera within 4 D of the scene (render_bands checks that per frame), so h must lie behind
+    // the plane by m_j + m_hit(h), m_hit(h) = 64 * 2^-24 * (10 k_h + 5) * D -- sixteen times that bound again.
+    // A wave whose hits lie on one triangle walks that triangle's list (k_shadow).
+    std::vector<uint2> hit_lists;
+    a->hit_pairs = a->hit_pairs_culled = 0;
+    // (at most 2^21 list records, 96 MB: a list per light form and triangle, each as long as the light's own at most)
+    if (a->hit_cull && n >= 2 && n <= kFlatMaxTris && (uint64_t)nb * n * (a->h_flat_tris.size() + kTriChunk) <= (1ull << 21)) {
+        struct Plane { double N[3], nn, m, m_hit; bool ok; };
+        std::vector<Plane> pl(n);
+        for (uint64_t j = 0; j < n; ++j) {
+            const float* p = a->positions.data() + j * 9;
+            double e1[3], e2[3];
+            for (int k = 0; k < 3; ++k) {
+                e1[k] = (double)(float)(p[3 + k] - p[k]);
+                e2[k] = (double)(float)(p[6 + k] - p[k]);
+            }
+            Plane& P = pl[j];
+            P.N[0] = e1[1] * e2[2] - e1[2] * e2[1];
+            P.N[1] = e1[2] * e2[0] - e1[0] * e2[2];
+            P.N[2] = e1[0] * e2[1] - e1[1] * e2[0];
+            P.nn = std::sqrt(P.N[0] * P.N[0] + P.N[1] * P.N[1] + P.N[2] * P.N[2]);
+            const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+            const double kappa = l1 * l2 / P.nn;
+            P.m = margin_scale * 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
+            P.m_hit = margin_scale * 64.0 * std::ldexp(1.0, -24) * (10.0 * kappa + 5.0) * D;
+            P.ok = P.nn > 0.0 && std::isfinite(P.nn) && std::isfinite(P.m) && std::isfinite(P.m_hit);
+        }
+        std::vector<uint8_t> behind(n * n, 0);  // behind[h * n + j]: all of triangle h lies behind the plane of j
+        for (uint64_t h = 0; h < n; ++h) {
+            if (!pl[h].ok) continue;
+            const float* q = a->positions.data() + h * 9;
+            for (uint64_t j = 0; j < n; ++j) {
+                if (j == h || !pl[j].ok) continue;
+                const float* p = a->positions.data() + j * 9;
+                bool all_behind = true;
+                for (int v = 0; v < 3 && all_behind; ++v) {
+                    double side = 0.0;
+                    for (int k = 0; k < 3; ++k) side += pl[j].N[k] * ((double)q[v * 3 + k] - (double)p[k]);
+                    all_behind = side / pl[j].nn <= -(pl[j].m + pl[h].m_hit);
+                }
+                behind[h * n + j] = all_behind ? 1 : 0;
+            }
+        }
+        hit_lists.resize(nb * n);
+        for (size_t l = 0; l < nb; ++l)
+            for (uint64_t h = 0; h < n; ++h) {
+                const size_t begin = all.size();
+                for (const LeafTri& t : a->h_flat_tris) {
+                    if (culled[l * n + t.tri]) continue;
+                    ++a->hit_pairs;
+                    if (behind[h * n + t.tri]) ++a->hit_pairs_culled;
+                    else all.push_back(t);
+                }
+                do all.push_back(zero); while ((all.size() - begin) % kTriChunk != 0);
+                hit_lists[l * n + h] = make_uint2((uint32_t)(begin - first[l]), (uint32_t)(all.size() - begin));
+            }
+    }
+    for (int k = 0; k < kTriChunk; ++k) all.push_back(zero);  // the pass reads whole blocks
+    HIP_TRY(a->d_light_flat.reserve(all.size()));
+    HIP_TRY(hipMemcpy(a->d_light_flat.p, all.data(), all.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    if (!hit_lists.empty()) {
+        HIP_TRY(a->d_hit_lists.reserve(hit_lists.size()));
+        HIP_TRY(hipMemcpy(a->d_hit_lists.p, hit_lists.data(), hit_lists.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
+    for (size_t l = 0; l < nb; ++l) {
+        forms[l].flat_tris = a->d_light_flat.p + first[l];
+        forms[l].n_flat_tris = count[l];
+        forms[l].hit_lists = hit_lists.empty() ? nullptr : a->d_hit_lists.p + l * n;
+    }
+    // the frames whose camera is near enough for the hit lists' margin: within 4 D of the middle of the scene's box
+    for (int k = 0; k < 3; ++k) a->scene_mid[k] = 0.5 * (lo[k] + hi[k]);
+    a->scene_diag = D;
+    return RT_OK;
+}
+
+// Clustered form, per light: every cluster's list without the culled triangles, and node records that point at them.
+int cluster_light_forms(const LightFormJob& J) {
+    LIGHT_FORM_JOB_LOCALS;
+    const size_t n_rec = a->h_cl_nodes.size();
+    std::vector<NodeRec> nodes;
+    std::vector<LeafTri> tris;
+    std::vector<size_t> tri_first(nb);
+    nodes.reserve(nb * n_rec);
+    for (size_t l = 0; l < nb; ++l) {
+        tri_first[l] = tris.size();
+        for (size_t r = 0; r < n_rec; ++r) {
+            NodeRec rec = a->h_cl_nodes[r];
+            const uint32_t begin = rec.pad[0], cnt = rec.pad[1];
+            if (cnt != 0) {
+                const size_t at = tris.size();
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const LeafTri& t = a->h_cl_tris[begin + k];
+                    if (t.pad0 != 0 && !culled[l * n + t.tri]) tris.push_back(t);  // (pad0 == 0: the old list's padding)
+                }
+                while ((tris.size() - at) % kTriChunk != 0) tris.push_back(zero);
+                rec.pad[0] = (uint32_t)(at - tri_first[l]);
+                rec.pad[1] = (uint32_t)(tris.size() - at);
+            }
+            nodes.push_back(rec);
+        }
+    }
+    for (int k = 0; k < kTriChunk; ++k) tris.push_back(zero);
+    HIP_TRY(a->d_light_cl_nodes.reserve(nodes.size()));
+    HIP_TRY(a->d_light_cl_tris.reserve(tris.size()));
+    HIP_TRY(hipMemcpy(a->d_light_cl_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(a->d_light_cl_tris.p, tris.data(), tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
+    for (size_t l = 0; l < nb; ++l) {
+        forms[l].cl_nodes = a->d_light_cl_nodes.p + l * n_rec;
+        forms[l].cl_tris = a->d_light_cl_tris.p + tri_first[l];
+    }
+    return RT_OK;
+}
+
+// Per-lane form (big trees), per light: the node records with the light's leaf ranges -- octants and subtrees left without
+// a triangle become empty -- and the geometry of the slots that remain.
+int lane_light_forms(const LightFormJob& J) {
+    LIGHT_FORM_JOB_LOCALS;
+    (void)zero;
+    const size_t n_rec = a->n_rec, n_slots = a->n_slots;
+    std::vector<NodeRec> nodes(n_rec);
+    std::vector<LeafTri> slots(n_slots);
+    HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
+    std::vector<NodeRec> all_nodes(nb * n_rec);
+    std::vector<std::vector<float>> geom_of(nb);
+    std::vector<size_t> geom_first(nb);
+    std::vector<uint32_t> root1(nb);
+    std::vector<int> bad(nb, 0);
+    // one host thread per light (at most kMaxLaneLightForms)
+    auto one_light = [&](size_t l) {
+        const uint8_t* cl = culled.data() + l * n;
+        std::vector<float>& geom = geom_of[l];
+        std::vector<uint32_t> pref(n_slots + 1);
+        // the slots that stay, in their order; pref[s] = how many of the slots before s stay
+        uint32_t kept = 0;
+        for (size_t sidx = 0; sidx < n_slots; ++sidx) {
+            pref[sidx] = kept;
+            kept += cl[slots[sidx].tri] ? 0u : 1u;
+        }
+        pref[n_slots] = kept;
+        geom.resize(((size_t)kept + kTriChunk) * 9, 0.0f);  // (a lane without a pair reads record 0 of its list)
+        for (size_t sidx = 0; sidx < n_slots; ++sidx) {
+            const LeafTri& t = slots[sidx];
+            if (cl[t.tri]) continue;
+            float* g = geom.data() + (size_t)pref[sidx] * 9;
+            g[0] = t.ax; g[1] = t.ay; g[2] = t.az; g[3] = t.e1x; g[4] = t.e1y; g[5] = t.e1z; g[6] = t.e2x; g[7] = t.e2y; g[8] = t.e2z;
+        }
+        // records bottom-up (children follow their parents in the array): leaf ranges renumbered, leaves and
+        // subtrees without a triangle become empty octants
+        NodeRec* out = all_nodes.data() + l * n_rec;
+        for (size_t r = n_rec; r-- > 0;) {
+            NodeRec rec = nodes[r];
+            uint32_t nonempty = 0;
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t i0 = rec.info[c][0], i1 = rec.info[c][1];
+                if (i1 == 0) continue;
+                if (i1 & kChildInternal) {
+                    if (i0 <= r || i0 >= n_rec) { bad[l] = 1; return; }  // (records not in breadth-first order)
+                    if (out[i0].nonempty == 0) rec.info[c][0] = rec.info[c][1] = 0;
+                } else {
+                    if ((uint64_t)i0 + i1 > n_slots) { bad[l] = 2; return; }  // (leaf range beyond the slot array)
+                    const uint32_t nb = pref[i0], nc = pref[i0 + i1] - pref[i0];
+                    rec.info[c][0] = nc ? nb : 0u;
+                    rec.info[c][1] = nc;
+                }
+                if (rec.info[c][1] != 0) nonempty |= 1u << c;
+            }
+            rec.nonempty = nonempty;
+            node_ordered_nonempty(nonempty, &rec.pad[1]);
+            out[r] = rec;
+        }
+        root1[l] = out[a->root_info[0]].nonempty != 0 ? a->root_info[1] : 0u;  // (0: nothing can occlude this light)
+    };
+    {
+        std::vector<std::thread> workers;
+        for (size_t l = 1; l < nb; ++l) workers.emplace_back(one_light, l);
+        one_light(0);
+        for (auto& w : workers) w.join();
+    }
+    for (size_t l = 0; l < nb; ++l)
+        if (bad[l]) return fail(RT_ERR_BUILD, "internal: the resident tree is not in the layout the per-light copies assume (%d)", bad[l]);
+    size_t geom_total = 0;
+    for (size_t l = 0; l < nb; ++l) {
+        geom_first[l] = geom_total;
+        geom_total += geom_of[l].size();
+    }
+    HIP_TRY(a->d_light_lane_nodes.reserve(all_nodes.size()));
+    HIP_TRY(a->d_light_lane_geom.reserve(geom_total));
+    HIP_TRY(hipMemcpy(a->d_light_lane_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    for (size_t l = 0; l < nb; ++l)
+        HIP_TRY(hipMemcpy(a->d_light_lane_geom.p + geom_first[l], geom_of[l].data(), geom_of[l].size() * sizeof(float), hipMemcpyHostToDevice));
+    for (size_t l = 0; l < nb; ++l) {
+        forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
+        forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
+        forms[l].lane_root_info1 = root1[l];
+        forms[l].lane_rec_base = (uint32_t)(l * n_rec);
+        forms[l].lane_slot_base = (uint32_t)(geom_first[l] / 9);
+    }
+    a->light_forms_lane = true;
+    return RT_OK;
+}
+#undef LIGHT_FORM_JOB_LOCALS
+
 // Per-light forms of the small-tree triangle list and of the clustered form.
 //
 // With back faces culled (collision_detection.h:31-35: d = dot(e1, cross(s, e2)) < epsilon is a miss) a triangle j can
@@ -957,214 +1204,13 @@ int make_light_forms(rt_ads* a, const std::vector<uint32_t>& light_tri) {
     const size_t nb = nl_build;  // sets of forms to build
     std::vector<LightForm> forms(nl_all);
     for (auto& f : forms) memset(&f, 0, sizeof f);
-    LeafTri zero;
-    memset(&zero, 0, sizeof zero);
-    if (have_flat) {  // per light: the triangles in their order, padded to whole blocks with records that list no leaf
-        std::vector<LeafTri> all;
-        std::vector<size_t> first(nb);
-        std::vector<uint32_t> count(nb);
-        for (size_t l = 0; l < nb; ++l) {
-            first[l] = all.size();
-            for (const LeafTri& t : a->h_flat_tris)
-                if (!culled[l * n + t.tri]) all.push_back(t);
-            do all.push_back(zero); while ((all.size() - first[l]) % kTriChunk != 0);  // (at least one record: a count of 0 means "no small-tree form")
-            count[l] = (uint32_t)(all.size() - first[l]);
-        }
-        // Per (light, hit triangle h): the light's list without the triangles j that have ALL of h behind their plane.
-        // A shadow ray that starts on h starts behind such a plane: running against N_j it moves away from the plane and
-        // its crossing lies at t < 0, running with N_j it meets a back face -- never an accepted occluder, by the same
-        // argument and the same margin m_j as above with the hit point in the light's place.  The hit point is not
-        // exactly on h: the reference's t of the hit is off by at most 4 * 2^-24 * (k_h (|q| + t) + t), and |q| + t stays
-        // below 10 D for a camera within 4 D of the scene (render_bands checks that per frame), so h must lie behind
-        // the plane by m_j + m_hit(h), m_hit(h) = 64 * 2^-24 * (10 k_h + 5) * D -- sixteen times that bound again.
-        // A wave whose hits lie on one triangle walks that triangle's list (k_shadow).
-        std::vector<uint2> hit_lists;
-        a->hit_pairs = a->hit_pairs_culled = 0;
-        // (at most 2^21 list records, 96 MB: a list per light form and triangle, each as long as the light's own at most)
-        if (a->hit_cull && n >= 2 && n <= kFlatMaxTris && (uint64_t)nb * n * (a->h_flat_tris.size() + kTriChunk) <= (1ull << 21)) {
-            struct Plane { double N[3], nn, m, m_hit; bool ok; };
-            std::vector<Plane> pl(n);
-            for (uint64_t j = 0; j < n; ++j) {
-                const float* p = a->positions.data() + j * 9;
-                double e1[3], e2[3];
-                for (int k = 0; k < 3; ++k) {
-                    e1[k] = (double)(float)(p[3 + k] - p[k]);
-                    e2[k] = (double)(float)(p[6 + k] - p[k]);
-                }
-                Plane& P = pl[j];
-                P.N[0] = e1[1] * e2[2] - e1[2] * e2[1];
-                P.N[1] = e1[2] * e2[0] - e1[0] * e2[2];
-                P.N[2] = e1[0] * e2[1] - e1[1] * e2[0];
-                P.nn = std::sqrt(P.N[0] * P.N[0] + P.N[1] * P.N[1] + P.N[2] * P.N[2]);
-                const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
-                const double kappa = l1 * l2 / P.nn;
-                P.m = margin_scale * 64.0 * std::ldexp(1.0, -24) * (2.0 * kappa + 1.0) * D;
-                P.m_hit = margin_scale * 64.0 * std::ldexp(1.0, -24) * (10.0 * kappa + 5.0) * D;
-                P.ok = P.nn > 0.0 && std::isfinite(P.nn) && std::isfinite(P.m) && std::isfinite(P.m_hit);
-            }
-            std::vector<uint8_t> behind(n * n, 0);  // behind[h * n + j]: all of triangle h lies behind the plane of j
-            for (uint64_t h = 0; h < n; ++h) {
-                if (!pl[h].ok) continue;
-                const float* q = a->positions.data() + h * 9;
-                for (uint64_t j = 0; j < n; ++j) {
-                    if (j == h || !pl[j].ok) continue;
-                    const float* p = a->positions.data() + j * 9;
-                    bool all_behind = true;
-                    for (int v = 0; v < 3 && all_behind; ++v) {
-                        double side = 0.0;
-                        for (int k = 0; k < 3; ++k) side += pl[j].N[k] * ((double)q[v * 3 + k] - (double)p[k]);
-                        all_behind = side / pl[j].nn <= -(pl[j].m + pl[h].m_hit);
-                    }
-                    behind[h * n + j] = all_behind ? 1 : 0;
-                }
-            }
-            hit_lists.resize(nb * n);
-            for (size_t l = 0; l < nb; ++l)
-                for (uint64_t h = 0; h < n; ++h) {
-                    const size_t begin = all.size();
-                    for (const LeafTri& t : a->h_flat_tris) {
-                        if (culled[l * n + t.tri]) continue;
-                        ++a->hit_pairs;
-                        if (behind[h * n + t.tri]) ++a->hit_pairs_culled;
-                        else all.push_back(t);
-                    }
-                    do all.push_back(zero); while ((all.size() - begin) % kTriChunk != 0);
-                    hit_lists[l * n + h] = make_uint2((uint32_t)(begin - first[l]), (uint32_t)(all.size() - begin));
-                }
-        }
-        for (int k = 0; k < kTriChunk; ++k) all.push_back(zero);  // the pass reads whole blocks
-        HIP_TRY(a->d_light_flat.reserve(all.size()));
-        HIP_TRY(hipMemcpy(a->d_light_flat.p, all.data(), all.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-        if (!hit_lists.empty()) {
-            HIP_TRY(a->d_hit_lists.reserve(hit_lists.size()));
-            HIP_TRY(hipMemcpy(a->d_hit_lists.p, hit_lists.data(), hit_lists.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        }
-        for (size_t l = 0; l < nb; ++l) {
-            forms[l].flat_tris = a->d_light_flat.p + first[l];
-            forms[l].n_flat_tris = count[l];
-            forms[l].hit_lists = hit_lists.empty() ? nullptr : a->d_hit_lists.p + l * n;
-        }
-        // the frames whose camera is near enough for the hit lists' margin: within 4 D of the middle of the scene's box
-        for (int k = 0; k < 3; ++k) a->scene_mid[k] = 0.5 * (lo[k] + hi[k]);
-        a->scene_diag = D;
-    }
-    if (have_cl) {  // per light: every cluster's list without the culled triangles, and node records that point at them
-        const size_t n_rec = a->h_cl_nodes.size();
-        std::vector<NodeRec> nodes;
-        std::vector<LeafTri> tris;
-        std::vector<size_t> tri_first(nb);
-        nodes.reserve(nb * n_rec);
-        for (size_t l = 0; l < nb; ++l) {
-            tri_first[l] = tris.size();
-            for (size_t r = 0; r < n_rec; ++r) {
-                NodeRec rec = a->h_cl_nodes[r];
-                const uint32_t begin = rec.pad[0], cnt = rec.pad[1];
-                if (cnt != 0) {
-                    const size_t at = tris.size();
-                    for (uint32_t k = 0; k < cnt; ++k) {
-                        const LeafTri& t = a->h_cl_tris[begin + k];
-                        if (t.pad0 != 0 && !culled[l * n + t.tri]) tris.push_back(t);  // (pad0 == 0: the old list's padding)
-                    }
-                    while ((tris.size() - at) % kTriChunk != 0) tris.push_back(zero);
-                    rec.pad[0] = (uint32_t)(at - tri_first[l]);
-                    rec.pad[1] = (uint32_t)(tris.size() - at);
-                }
-                nodes.push_back(rec);
-            }
-        }
-        for (int k = 0; k < kTriChunk; ++k) tris.push_back(zero);
-        HIP_TRY(a->d_light_cl_nodes.reserve(nodes.size()));
-        HIP_TRY(a->d_light_cl_tris.reserve(tris.size()));
-        HIP_TRY(hipMemcpy(a->d_light_cl_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(a->d_light_cl_tris.p, tris.data(), tris.size() * sizeof(LeafTri), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nb; ++l) {
-            forms[l].cl_nodes = a->d_light_cl_nodes.p + l * n_rec;
-            forms[l].cl_tris = a->d_light_cl_tris.p + tri_first[l];
-        }
-    }
-    if (have_lane) {
-        const size_t n_rec = a->n_rec, n_slots = a->n_slots;
-        std::vector<NodeRec> nodes(n_rec);
-        std::vector<LeafTri> slots(n_slots);
-        HIP_TRY(hipMemcpy(nodes.data(), a->d_nodes.p, n_rec * sizeof(NodeRec), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(slots.data(), a->d_slots.p, n_slots * sizeof(LeafTri), hipMemcpyDeviceToHost));
-        std::vector<NodeRec> all_nodes(nb * n_rec);
-        std::vector<std::vector<float>> geom_of(nb);
-        std::vector<size_t> geom_first(nb);
-        std::vector<uint32_t> root1(nb);
-        std::vector<int> bad(nb, 0);
-        // one host thread per light (at most kMaxLaneLightForms)
-        auto one_light = [&](size_t l) {
-            const uint8_t* cl = culled.data() + l * n;
-            std::vector<float>& geom = geom_of[l];
-            std::vector<uint32_t> pref(n_slots + 1);
-            // the slots that stay, in their order; pref[s] = how many of the slots before s stay
-            uint32_t kept = 0;
-            for (size_t sidx = 0; sidx < n_slots; ++sidx) {
-                pref[sidx] = kept;
-                kept += cl[slots[sidx].tri] ? 0u : 1u;
-            }
-            pref[n_slots] = kept;
-            geom.resize(((size_t)kept + kTriChunk) * 9, 0.0f);  // (a lane without a pair reads record 0 of its list)
-            for (size_t sidx = 0; sidx < n_slots; ++sidx) {
-                const LeafTri& t = slots[sidx];
-                if (cl[t.tri]) continue;
-                float* g = geom.data() + (size_t)pref[sidx] * 9;
-                g[0] = t.ax; g[1] = t.ay; g[2] = t.az; g[3] = t.e1x; g[4] = t.e1y; g[5] = t.e1z; g[6] = t.e2x; g[7] = t.e2y; g[8] = t.e2z;
-            }
-            // records bottom-up (children follow their parents in the array): leaf ranges renumbered, leaves and
-            // subtrees without a triangle become empty octants
-            NodeRec* out = all_nodes.data() + l * n_rec;
-            for (size_t r = n_rec; r-- > 0;) {
-                NodeRec rec = nodes[r];
-                uint32_t nonempty = 0;
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t i0 = rec.info[c][0], i1 = rec.info[c][1];
-                    if (i1 == 0) continue;
-                    if (i1 & kChildInternal) {
-                        if (i0 <= r || i0 >= n_rec) { bad[l] = 1; return; }  // (records not in breadth-first order)
-                        if (out[i0].nonempty == 0) rec.info[c][0] = rec.info[c][1] = 0;
-                    } else {
-                        if ((uint64_t)i0 + i1 > n_slots) { bad[l] = 2; return; }  // (leaf range beyond the slot array)
-                        const uint32_t nb = pref[i0], nc = pref[i0 + i1] - pref[i0];
-                        rec.info[c][0] = nc ? nb : 0u;
-                        rec.info[c][1] = nc;
-                    }
-                    if (rec.info[c][1] != 0) nonempty |= 1u << c;
-                }
-                rec.nonempty = nonempty;
-                node_ordered_nonempty(nonempty, &rec.pad[1]);
-                out[r] = rec;
-            }
-            root1[l] = out[a->root_info[0]].nonempty != 0 ? a->root_info[1] : 0u;  // (0: nothing can occlude this light)
-        };
-        {
-            std::vector<std::thread> workers;
-            for (size_t l = 1; l < nb; ++l) workers.emplace_back(one_light, l);
-            one_light(0);
-            for (auto& w : workers) w.join();
-        }
-        for (size_t l = 0; l < nb; ++l)
-            if (bad[l]) return fail(RT_ERR_BUILD, "internal: the resident tree is not in the layout the per-light copies assume (%d)", bad[l]);
-        size_t geom_total = 0;
-        for (size_t l = 0; l < nb; ++l) {
-            geom_first[l] = geom_total;
-            geom_total += geom_of[l].size();
-        }
-        HIP_TRY(a->d_light_lane_nodes.reserve(all_nodes.size()));
-        HIP_TRY(a->d_light_lane_geom.reserve(geom_total));
-        HIP_TRY(hipMemcpy(a->d_light_lane_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nb; ++l)
-            HIP_TRY(hipMemcpy(a->d_light_lane_geom.p + geom_first[l], geom_of[l].data(), geom_of[l].size() * sizeof(float), hipMemcpyHostToDevice));
-        for (size_t l = 0; l < nb; ++l) {
-            forms[l].lane_nodes = a->d_light_lane_nodes.p + l * n_rec;
-            forms[l].lane_slot_geom = a->d_light_lane_geom.p + geom_first[l];
-            forms[l].lane_root_info1 = root1[l];
-            forms[l].lane_rec_base = (uint32_t)(l * n_rec);
-            forms[l].lane_slot_base = (uint32_t)(geom_first[l] / 9);
-        }
-        a->light_forms_lane = true;
-    }
+    const LightFormJob job{a, n, nb, culled, forms, D, margin_scale, lo, hi};
+    if (have_flat)
+        if (int rc = flat_light_lists(job)) return rc;
+    if (have_cl)
+        if (int rc = cluster_light_forms(job)) return rc;
+    if (have_lane)
+        if (int rc = lane_light_forms(job)) return rc;
     for (size_t l = nb; l < nl_all; ++l) forms[l] = forms[0];  // (merged: every light points at the one set)
     HIP_TRY(a->d_light_forms.reserve(nl_all));
     HIP_TRY(hipMemcpy(a->d_light_forms.p, forms.data(), nl_all * sizeof(LightForm), hipMemcpyHostToDevice));
