@@ -75,6 +75,8 @@ WORKLOADS = {
 # "streams": sub-frames a rt_render call of the workload runs concurrently (rt_ads_set_render_streams); pays where a frame
 # is a long chain of small recursion levels
 DEFAULT_WORKLOAD = "cornell_original_blinn_spt16_1080p"
+# shortest untimed warm-up of a frame loop, seconds (FrameLoop.warm)
+PREWARM_S = float(os.environ.get("RT_BENCH_PREWARM_S", "0.05"))
 # frames of the other configurations that the default single-GPU run appends to its line
 OTHER_WORKLOADS = {"cornell_sphere_blinn_smooth_spp4_1080p": 4, "synthetic_ico8_phong_4k": 5, "cornell_original_blinn_spp64_spt32_4k": 2}
 # ... and the ones a multi-GPU run appends (band-split over the ranks): the workloads the scaling target names
@@ -290,6 +292,7 @@ class FrameLoop:
     def __init__(self, ads, rt, wl, rank, world, dist, torch, overlap=True, use_thread=True, depth=0, device="cuda"):
         from raytracer_amd import distributed as rd
         self.ads, self.torch, self.dist = ads, torch, dist
+        self.device = device
         self.on_gpu = str(device).startswith("cuda")  # ("cpu": the loop's bookkeeping under test, with gloo and a stand-in renderer)
         self.H, self.W = wl["height"], wl["width"]
         self.cfg = rt.make_render_config(band_rank=rank, band_world=world, **render_kwargs(wl))
@@ -375,8 +378,14 @@ class FrameLoop:
 
     def warm(self, frames=1):
         """Untimed frames through the same loop.  Every frame slot of the library allocates its level buffers on its first
-        frame, so a loop with frames in flight is warm only after each slot has rendered one."""
-        self.timed(max(frames, 2 * self.depth))
+        frame, so a loop with frames in flight is warm only after each slot has rendered one.  The GPU also needs some
+        twenty milliseconds of work to reach its clocks (a 1.6 ms frame takes 1.75 ms in the first ten): the warm-up lasts
+        at least PREWARM_S, with a number of further frames that every rank derives from the same (slowest) rank's time."""
+        n = max(frames, 2 * self.depth)
+        spent = max_over_ranks(self.timed(n), self.dist, self.torch, device=self.device)
+        if spent < PREWARM_S:
+            more = min(int((PREWARM_S - spent) / max(spent / n, 1e-6)) + 1, 400)
+            self.timed(max(more, self.depth))
 
     def last_frame(self):
         return self.frames[(self.n - 1) % len(self.frames)]
@@ -389,10 +398,10 @@ class FrameLoop:
             self.worker = None
 
 
-def max_over_ranks(seconds, dist, torch):
+def max_over_ranks(seconds, dist, torch, device="cuda"):
     if dist is None:
         return seconds
-    tt = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
 

@@ -189,6 +189,7 @@ def _frame_loop_worker(rank, world, port, out_path, depth):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         wl = dict(bench.WORKLOADS["cornell_original_blinn_spt4_256"], width=W, height=H)
+        bench.PREWARM_S = 0.0  # (the frames are counted below: no warm-up by the clock)
         ads = _StandInRenderer(rank, world)
         loop = bench.FrameLoop(ads, rt, wl, rank, world, dist, torch, depth=depth, device="cpu")
         ads.loop = loop
