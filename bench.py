@@ -15,6 +15,10 @@ dependent launches that cannot fill a GPU by itself.  With N = 1 the timed loop 
 per-kernel times are then those of kernels running alone) and the rate with frames in flight is reported beside it
 (`frames_in_flight`).
 
+The W warm-up frames are followed by as many further untimed ones as it takes to have rendered for 50 ms
+(RT_BENCH_PREWARM_S): the GPU reaches its clocks only after some twenty milliseconds of work, and a 1.6 ms frame takes
+1.75 ms until then.  Then exactly K frames are timed.
+
 Prints ONE JSON line on rank 0.  metric = Mrays/s, one ray = one Search-equivalent query of the
 reference (primary, secondary or shadow).
 
